@@ -1,0 +1,216 @@
+/*
+ * xee.h -- C-ABI of libxee, the MI355X (gfx950) implementation of the elliptic streamfunction
+ * solve and energy-efficiency diagnostic of meteorologytoday/XLab-EE-fortran.
+ *
+ * This header is the drop-in boundary.  Every entry point names the reference interface it
+ * replaces (path:line under the reference tree).  Plain C types only; no HIP / torch types.
+ *
+ * Conventions shared by all entry points
+ *   - float = IEEE binary32, int = int32; all arrays are caller-owned.
+ *   - 2-D arrays use the reference's Fortran layout f(n1,n2), column-major: C index j*n1 + i with
+ *     i the r index (fastest) and j the z index -- identical to the reference's .bin files
+ *     (xtt-lib-fortran/field_tools.f90:30-76) and to a numpy (n2,n1) C-order array.
+ *   - `coe` on the Tier-1 calls keeps the reference's AoS layout coe(9,nx,ny).
+ *   - Every function returns a status code (XEE_OK == 0).  Nothing calls exit(): where the
+ *     reference STOPs (elliptic_tools.f90:126-129) the status is XEE_ERR_INVALID_CRITERIA and the
+ *     Fortran shim (xlab-ee-fortran_amd/fortran/elliptic_tools.f90) performs the STOP.
+ *   - Results are bit-identical to the reference's fp32 arithmetic (no FMA contraction,
+ *     correctly-rounded division/sqrt, sequential fp32 sums in the reference's loop order).
+ *   - There is NO CPU fallback: without a usable gfx950 device every compute entry point returns
+ *     XEE_ERR_NO_DEVICE.
+ */
+#ifndef XEE_H
+#define XEE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XEE_VERSION 100
+
+/* status codes */
+#define XEE_OK                    0
+#define XEE_ERR_INVALID_CRITERIA  1   /* strategy_r1 <= 0 and strategy_r2 <= 0 (elliptic_tools.f90:126-129) */
+#define XEE_ERR_INVALID_ARGUMENT  2
+#define XEE_ERR_NO_DEVICE         3
+#define XEE_ERR_HIP               4
+#define XEE_ERR_ALLOC             5
+
+/* solver error bitmask, xtt-lib-fortran/elliptic_tools.f90:3-4 */
+#define XEE_ERRBIT_OVER_MAX_ITERATION 1
+#define XEE_ERRBIT_EXPLODE            2
+
+/* operator variants, src/diagnose/variables.f90:13-15 and diagnose.f90:6,33 */
+#define XEE_BAROTROPIC 0   /* solverB_B := 0 */
+#define XEE_BAROCLINIC 1   /* solverB_B := saved_solverB_B */
+
+int         xee_version(void);
+const char *xee_last_error(void);          /* text of the last failure on this thread */
+int         xee_device_count(int *count);  /* number of visible HIP devices (0 is not an error) */
+
+/* ---------------------------------------------------------------------------------------------
+ * Tier 1 -- drop-in replacements, host arrays in / host arrays out.
+ * ------------------------------------------------------------------------------------------- */
+
+/* replaces cal_coe, xtt-lib-fortran/elliptic_tools.f90:8-60.
+ * a(nx-1,ny-2), b(nx-1,ny-1), c(nx-2,ny-1) -> coe(9,nx,ny); only interior entries are written.
+ * *err: 1 on entry to the computation, 0 on success (as the reference). */
+int xee_cal_coe(const float *a, const float *b, const float *c, float *coe,
+                float dx, float dy, int nx, int ny, int *err);
+
+/* replaces do_elliptic, elliptic_tools.f90:64-90.  Interior of outdat only; *err := 1 (sic). */
+int xee_do_elliptic(const float *psi, const float *coe, float *outdat, int nx, int ny, int *err);
+
+/* replaces solve_elliptic, elliptic_tools.f90:93-265.  *max_iter, *strategy_r1, *strategy_r2 and
+ * *err are overwritten with iterations used, final RMS residual, final |ratio| and the error
+ * bitmask (:253).  `workspace` is scratch (unspecified content on return, as for the reference's
+ * callers).  debug: 1/2 echo the inputs, 2 also prints the per-check trace (:146-158,:202-204). */
+int xee_solve_elliptic(int *max_iter, int check_step, int converge_time, int lost_rate,
+                       float *strategy_r1, float *strategy_r2, float alpha,
+                       float *dat, const float *coe, const float *f, float *workspace,
+                       int nx, int ny, int *err, int debug);
+
+/* replaces judge_error, elliptic_tools.f90:333-358 (prints the same texts to stdout). */
+void xee_judge_error(int err);
+
+/* replaces the 1-D profile set-up, src/diagnose/initialize-variables.f90:44-67 (+ the domain lines of
+ * read-input.f90:55-76).  HOST-side work by design: rho needs glibc powf and the spherical geometry
+ * glibc cosf/sinf, which no device libm reproduces bit for bit (hard part 5).
+ * geometry 0: domain = {Lr1, Lr2, Lz1, Lz2}; geometry 1 (spherical): domain = {planet_radius, Lz1, Lz2}
+ * with latitudes in DEGREES fed to cos/sin exactly as the reference does (quirk 9).
+ * density_mode 0: DENSITY_NORMAL, 1: DENSITY_BOUSSINESQ.  sin_table may be NULL. */
+int xee_profiles(int geometry, int density_mode, const float *domain, int nr, int nz,
+                 float *ra, float *za, float *rcuva, float *exner, float *rho, float *sin_table,
+                 float *dr, float *dz);
+
+/* replaces the solver-coefficient assembly loops, src/diagnose/initialize-variables.f90:72-95.
+ * rhoA/rhoB/rhoC (nr,nz), rcuva[nr], rho[nz] -> solverA (nr-1,nz-2), solverB (nr-1,nz-1),
+ * solverC (nr-2,nz-1). */
+int xee_solver_coefficients(const float *rhoA, const float *rhoB, const float *rhoC,
+                            const float *rcuva, const float *rho,
+                            float *solverA, float *solverB, float *solverC, int nr, int nz);
+
+/* replaces cal_eta, src/diagnose/quick-tools1.f90:1-13 (internal procedure of program main that
+ * reads host-associated ra, rcuva, rho, exner -- passed explicitly here).  eta (nr-1,nz). */
+int xee_cal_eta(const float *rchi, float *eta, const float *ra, const float *rcuva,
+                const float *rho, const float *exner, int nr, int nz);
+
+/* replaces cal_uw, src/diagnose/quick-tools1.f90:15-41.  u (nr,nz-1), w (nr-1,nz). */
+int xee_cal_uw(const float *rpsi, float *u, float *w, const float *ra, const float *za,
+               const float *rcuva, const float *rho, int nr, int nz);
+
+/* replaces integrate_weight_B / cal_sum_Q / cal_sum_wtheta,
+ * src/old-diagnose/diagnose.f90:1029-1048,1050-1071,1094-1113: weight (nr-1,nz-1) -> *sum,
+ * sequential fp32 accumulation in the reference's order (i outer, j inner). */
+int xee_integrate_weight_B(const float *weight, const float *ra, const float *za,
+                           const float *rcuva, const float *rho, int nr, int nz, float *sum);
+
+/* replaces cal_sum_Qeta, src/old-diagnose/diagnose.f90:1073-1092.  Q (nr-1,nz-1), eta (nr-1,nz). */
+int xee_cal_sum_Qeta(const float *Q, const float *eta, const float *ra, const float *za,
+                     const float *rcuva, const float *rho, int nr, int nz, float *sum);
+
+/* replaces cal_wtheta, src/old-diagnose/diagnose.f90:1117-1127. */
+int xee_cal_wtheta(const float *w_A, const float *theta_B, float *wtheta_B, int nr, int nz);
+
+/* replaces the RHS source-term assembly of the legacy sweep,
+ * src/old-diagnose/diagnose.f90:383-387 + 395-406 (thermal: g0/theta0 d/dr(Q/(Cp exner)) averaged
+ * to O points) and :523-538 (f = -1/4 sum of the 4 neighbouring B cells).  Outputs are (nr,nz). */
+int xee_rhs_thermal(const float *Q_B, const float *ra, const float *exner, float *rhs_O, int nr, int nz);
+int xee_rhs_from_B(const float *b_B, float *f_O, int nr, int nz);
+
+/* ---------------------------------------------------------------------------------------------
+ * Tier 2 -- device-resident ensemble of independent cases on ONE GPU.
+ * All members share nr, nz and the 1-D profiles; each has its own A, B, C, forcing, bc_init, Q.
+ * ------------------------------------------------------------------------------------------- */
+
+typedef struct xee_ensemble xee_ensemble_t;
+
+/* per-member field identifiers for upload / download / device_plane */
+enum {
+    XEE_F_A = 0,        /* rhoA_in (nr,nz)            initialize-variables.f90:33 */
+    XEE_F_B = 1,        /* rhoB_in (nr,nz)            :34 */
+    XEE_F_C = 2,        /* rhoC_in (nr,nz)            :35 */
+    XEE_F_BC_INIT = 3,  /* bc_init_in (nr,nz)         :36 */
+    XEE_F_FORCING = 4,  /* f (nr,nz)                  :38-42, diagnose.f90:2 */
+    XEE_F_PSI = 5,      /* strf: solution (nr,nz)     diagnose.f90:13-15 */
+    XEE_F_SOLVER_A = 6, /* solverA_A (nr-1,nz-2)      initialize-variables.f90:72-77 */
+    XEE_F_SOLVER_B = 7, /* solverB_B (nr-1,nz-1)      :80-86 */
+    XEE_F_SOLVER_C = 8, /* solverC_C (nr-2,nz-1)      :90-95 */
+    XEE_F_ETA = 9,      /* eta (nr-1,nz)              quick-tools1.f90:1-13 */
+    XEE_F_U = 10,       /* u_C (nr,nz-1)              quick-tools1.f90:15-41 */
+    XEE_F_W = 11,       /* w_A (nr-1,nz) */
+    XEE_F_Q = 12,       /* heating Q on B cells (nr-1,nz-1), EE scalars (old-diagnose :1050-1092) */
+    XEE_F_RESIDUAL = 13,/* residual plane of the last check iteration (nr,nz), interior valid */
+    XEE_F_COE0 = 16     /* XEE_F_COE0+k, k=0..8: coefficient plane k (nr,nz), interior valid */
+};
+
+/* One fixed-size record per case; this is what the multi-GPU gather moves. */
+typedef struct {
+    int32_t case_id;     /* global case index (caller-assigned, see xee_ensemble_set_case_ids) */
+    int32_t iters;       /* iterations used           (max_iter on return, elliptic_tools.f90:253) */
+    int32_t err_bits;    /* XEE_ERRBIT_*              */
+    int32_t reserved;
+    float   err_now;     /* final RMS residual        (strategy_r1 on return) */
+    float   ratio;       /* final |ratio|             (strategy_r2 on return) */
+    float   sum_Q;       /* integrate_weight_B(Q)     old-diagnose :1069 */
+    float   sum_Qeta;    /* cal_sum_Qeta(Q, eta)      old-diagnose :1073-1092 */
+    float   efficiency;  /* sum_Qeta / sum_Q          old-diagnose :792-793 */
+    float   scalars[23]; /* reserved for further EE scalars */
+} xee_case_record_t;     /* 128 bytes */
+
+typedef struct {
+    double solve_ms;        /* device time of the last xee_ensemble_solve (HIP events on its stream) */
+    double sweep_ms;        /* of which: sweep kernels (events around the sweep launches only) */
+    int64_t sweep_launches; /* number of sweep kernel launches in the last solve */
+    int64_t iterations;     /* Jacobi iterations enqueued in the last solve (per member) */
+    int64_t check_launches; /* residual-norm / state-machine launches */
+} xee_timing_t;
+
+/* flags of xee_ensemble_solve */
+#define XEE_SOLVE_DEFAULT        0
+#define XEE_SOLVE_SINGLE_STEP    1   /* one iteration per launch (streaming kernel only)          */
+#define XEE_SOLVE_KEEP_PSI       2   /* start from the current PSI instead of copying BC_INIT      */
+#define XEE_SOLVE_TRACE          4   /* per-check "Iter/err_now/ratio" trace (debug==2, :202-204)    */
+
+int xee_ensemble_create(xee_ensemble_t **ens, int nr, int nz, int n_members, int device);
+int xee_ensemble_destroy(xee_ensemble_t *ens);
+/* run on a caller-provided hipStream_t (e.g. torch's current stream); NULL = the ensemble's own */
+int xee_ensemble_set_stream(xee_ensemble_t *ens, void *hip_stream);
+int xee_ensemble_set_case_ids(xee_ensemble_t *ens, int first_case_id);
+/* A13 profiles are host-side work (glibc powf/cosf, initialize-variables.f90:44-67); hand them in */
+int xee_ensemble_set_profiles(xee_ensemble_t *ens, const float *ra, const float *za,
+                              const float *rcuva, const float *rho, const float *exner,
+                              float dr, float dz);
+/* host <-> device for `count` consecutive members starting at `first`; host holds count packed
+ * (n1,n2) arrays of the field's logical shape */
+int xee_ensemble_upload(xee_ensemble_t *ens, int field, int first, int count, const float *host);
+int xee_ensemble_download(xee_ensemble_t *ens, int field, int first, int count, float *host);
+/* raw device view of a field so that a producer already on the GPU can fill it in place:
+ * element (i,j) of member m lives at dptr[m*member_stride + j*pitch + i] */
+int xee_ensemble_device_plane(xee_ensemble_t *ens, int field, void **dptr, int *pitch,
+                              size_t *member_stride, int *n1, int *n2);
+/* f := -rhoB_in (DYNAMIC_EFFICIENCY, initialize-variables.f90:40-42) */
+int xee_ensemble_forcing_from_B(xee_ensemble_t *ens);
+/* solver coefficients (K1) then the 9-point stencil (K2) for the chosen operator variant */
+int xee_ensemble_assemble(xee_ensemble_t *ens, int variant);
+/* strf := bc_init_in, then solve_elliptic on every member; per-member results in the records */
+int xee_ensemble_solve(xee_ensemble_t *ens, int max_iter, int check_step, int converge_time,
+                       int lost_rate, float strategy_r1, float strategy_r2, float alpha, int flags);
+int xee_ensemble_cal_eta(xee_ensemble_t *ens);
+int xee_ensemble_cal_uw(xee_ensemble_t *ens);
+/* sum_Q, sum_Qeta, efficiency from Q and the current eta (order-exact fp32 sums) */
+int xee_ensemble_ee_scalars(xee_ensemble_t *ens);
+int xee_ensemble_records(xee_ensemble_t *ens, xee_case_record_t *out /* n_members */);
+int xee_ensemble_timing(xee_ensemble_t *ens, xee_timing_t *out);
+/* measurement aid: `iters` bare sweep iterations (no checks) of kernel `variant`
+ * (0 = streaming, 1 = temporally blocked) between HIP events; does not touch the records */
+int xee_ensemble_time_sweeps(xee_ensemble_t *ens, int iters, int variant, float alpha,
+                             double *elapsed_ms, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

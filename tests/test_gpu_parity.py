@@ -1,0 +1,216 @@
+"""GPU parity tests: the HIP path, called through the C-ABI (include/xee.h via ctypes), against the
+oracle on the same inputs and against the reference's own golden outputs.  fp32 fields and scalars are
+compared BIT FOR BIT -- the meaning of the north star's 1e-10 / 1e-12 tolerances for real(4) data."""
+import numpy as np
+import pytest
+
+import orchelp as H
+import xee_pkg
+
+pytestmark = pytest.mark.gpu
+
+xee = xee_pkg.load()
+
+
+def biteq(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert xee.device_count() >= 1, "GPU tests need a device; libxee has no CPU fallback"
+
+
+# ---- kernel level -----------------------------------------------------------------------------
+
+@pytest.mark.parametrize("nr,nz", [(64, 48), (37, 29), (200, 200), (257, 33), (1024, 64)])
+def test_solver_coefficients_and_cal_coe(nr, nz):
+    A, B, Cc, bc = H.rich_inputs(nr, nz, seed=nr + nz)
+    prof = H.profiles(nr, nz, 0, 0, (0.0, 2.0e5, 0.0, 1.5e4))
+    sA, sB, sC = H.solver_coefficients(A, B, Cc, prof["rcuva"], prof["rho"])
+    gA, gB, gC = xee.solver_coefficients(A, B, Cc, prof["rcuva"], prof["rho"])
+    assert biteq(gA, sA) and biteq(gB, sB) and biteq(gC, sC)
+    want = H.cal_coe(sA, sB, sC, prof["dr"], prof["dz"], nr, nz)
+    sentinel = np.full((nz, nr, 9), 7.25, np.float32)
+    got, err = xee.cal_coe(sA, sB, sC, prof["dr"], prof["dz"], nr, nz, coe=sentinel)
+    assert err == 0
+    assert biteq(got[1:-1, 1:-1], want[1:-1, 1:-1])
+    # rim entries are not written (the reference leaves them untouched)
+    assert np.all(got[0] == 7.25) and np.all(got[-1] == 7.25) and np.all(got[:, 0] == 7.25) and np.all(got[:, -1] == 7.25)
+
+
+@pytest.mark.parametrize("nr,nz", [(64, 48), (130, 21)])
+def test_do_elliptic(nr, nz):
+    A, B, Cc, bc = H.rich_inputs(nr, nz, seed=5)
+    prof = H.profiles(nr, nz)
+    sA, sB, sC = H.solver_coefficients(A, B, Cc, prof["rcuva"], prof["rho"])
+    coe = H.cal_coe(sA, sB, sC, prof["dr"], prof["dz"], nr, nz)
+    want = np.full((nz, nr), -3.5, np.float32)
+    e = __import__("ctypes").c_int(0)
+    H.oracle().orc_do_elliptic(bc, coe, want, nr, nz, e)
+    got, err = xee.do_elliptic(bc, coe, outdat=np.full((nz, nr), -3.5, np.float32))
+    assert err == 1 and biteq(got, want)
+
+
+@pytest.mark.parametrize("nr,nz,crit", [
+    (64, 48, (1e-8, -1.0, 300, 0.9)), (37, 29, (5e-3, 5e-3, 5000, 1.0)), (37, 29, (-1.0, 1e-3, 3000, 0.8)),
+    (64, 48, (1e-8, -1.0, 150, 1.0)), (64, 48, (1e-8, -1.0, 99, 1.0)), (200, 120, (1e-8, -1.0, 400, 1.0)),
+    (300, 40, (1e-8, -1.0, 201, 0.7)),
+])
+def test_solve_elliptic_drop_in(nr, nz, crit):
+    """xee_solve_elliptic vs the oracle incl. the in/out scalars (iterations, residues, err bits)."""
+    r1, r2, mi, al = crit
+    A, B, Cc, bc = H.rich_inputs(nr, nz, seed=nr * 3 + nz)
+    prof = H.profiles(nr, nz, 0, 0, (0.0, 2.0e5, 0.0, 1.5e4))
+    sA, sB, sC = H.solver_coefficients(A, B, Cc, prof["rcuva"], prof["rho"])
+    coe = H.cal_coe(sA, sB, sC, prof["dr"], prof["dz"], nr, nz)
+    f = (-B).astype(np.float32)
+    want = H.solve(bc, coe, f, mi, r1, r2, al)
+    got = xee.solve_elliptic(bc, coe, f, mi, r1, r2, al)
+    assert biteq(got[0], want[0])
+    assert got[1] == want[1] and got[2] == want[2]
+    assert got[3].tobytes() == want[3].tobytes() and got[4].tobytes() == want[4].tobytes()
+
+
+def test_solve_rejects_both_criteria_off():
+    A, B, Cc, bc = H.rich_inputs(16, 12)
+    with pytest.raises(xee.XeeError) as ei:
+        xee.solve_elliptic(bc, np.zeros((12, 16, 9), np.float32), B, 10, -1.0, 0.0, 1.0)
+    assert ei.value.status == 1
+
+
+def test_eta_uw_and_integrals():
+    nr, nz = 96, 72
+    A, B, Cc, bc = H.rich_inputs(nr, nz, seed=21)
+    prof = H.profiles(nr, nz, 0, 0, (0.0, 2.0e5, 0.0, 1.5e4))
+    psi = bc
+    assert biteq(xee.cal_eta(psi, prof), H.cal_eta(psi, prof))
+    u, w = xee.cal_uw(psi, prof)
+    uo, wo = H.cal_uw(psi, prof)
+    assert biteq(u, uo) and biteq(w, wo)
+    rng = np.random.default_rng(2)
+    Q = np.exp(-((np.linspace(0, 1, nr - 1)[None, :] - 0.3) / 0.1) ** 2 - ((np.linspace(0, 1, nz - 1)[:, None] - 0.5) / 0.2) ** 2)
+    Q = (Q + 1e-3 * rng.standard_normal(Q.shape)).astype(np.float32)
+    eta = H.cal_eta(psi, prof)
+    assert xee.integrate_weight_B(Q, prof).tobytes() == H.integrate_weight_B(Q, prof).tobytes()
+    assert xee.cal_sum_Qeta(Q, eta, prof).tobytes() == H.cal_sum_Qeta(Q, eta, prof).tobytes()
+    wt = np.zeros((nz - 1, nr - 1), np.float32)
+    H.oracle().orc_cal_wtheta(wo, Q, wt, nr, nz)
+    assert biteq(xee.cal_wtheta(wo, Q), wt)
+
+
+def test_rhs_assembly():
+    nr, nz = 80, 56
+    prof = H.profiles(nr, nz, 0, 0, (0.0, 2.0e5, 0.0, 1.5e4))
+    rng = np.random.default_rng(9)
+    Q = rng.standard_normal((nz - 1, nr - 1)).astype(np.float32)
+    JJ = np.zeros_like(Q)
+    H.oracle().orc_JJ_B(Q, prof["exner"], JJ, nr, nz)
+    rhs = np.zeros((nz, nr), np.float32)
+    wk = np.zeros((nz - 1, nr), np.float32)
+    H.oracle().orc_rhs_thm(JJ, rhs, wk, prof["ra"], nr, nz)
+    assert biteq(xee.rhs_thermal(Q, prof["ra"], prof["exner"]), rhs)
+    fO = np.zeros((nz, nr), np.float32)
+    H.oracle().orc_f_from_B(Q, fO, nr, nz)
+    assert biteq(xee.rhs_from_B(Q), fO)
+
+
+# ---- whole case vs the reference's golden outputs ---------------------------------------------
+
+GOLDEN_CASES = ["p128x64_test1", "s64x48_baroall", "s64x48_seccirc", "s64x48_converge", "s64x48_spherical"]
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_whole_case_matches_reference_golden(name, golden_hashes):
+    g = np.load(H.GOLDEN / f"{name}.npz")
+    rec = golden_hashes[name]
+    cfg = rec["cfg"]
+    out = xee.diagnose_case(g["in_A"], g["in_B"], g["in_C"], g["in_bc"],
+                            g["in_forcing"] if "in_forcing" in g.files else None,
+                            mode=tuple(cfg.get("mode", ("DYNAMIC_EFFICIENCY", "CYLINDRICAL", "DENSITY_NORMAL", "BAROTROPIC"))),
+                            domain=tuple(cfg.get("domain", (0.0, 1.0, 0.0, 1.0))),
+                            r1=cfg["r1"], r2=cfg["r2"], max_iter=cfg["max_iter"], alpha=cfg["alpha"])
+    sA, sB, sC = out["solver"]
+    assert biteq(sA[0], g["out_solver_a-sA.bin"]) and biteq(sB[0], g["out_solver_b-B.bin"]) and biteq(sC[0], g["out_solver_c-sC.bin"])
+    variants = [v for v in ("BAROTROPIC", "BAROCLINIC") if v in out]
+    assert len(variants) == len(rec["relax"])
+    for v, (iters, r1s, r2s) in zip(variants, rec["relax"]):
+        res = out[v]
+        assert int(res["iters"][0]) == iters
+        assert float(res["r1"][0]) == pytest.approx(float(r1s), rel=2e-7)
+        assert float(res["r2"][0]) == pytest.approx(float(r2s), rel=2e-7)
+        for key, fn in (("eta", f"eta-[{v}]-A.bin"), ("psi", f"rchi-[{v}]-O.bin"), ("psi", f"rpsi-[{v}]-O.bin"),
+                        ("u", f"u-[{v}]-C.bin"), ("w", f"w-[{v}]-A.bin")):
+            if "out_" + fn in g.files:
+                assert biteq(res[key][0], g["out_" + fn]), (v, fn)
+
+
+def test_test1_fixture_on_gpu():
+    """The shipped fixture: 200x200 -> 17,900 iterations; md5 anchors of BASELINE.md section 4."""
+    A, B, Cc, bc = H.test1_inputs(200, 200)
+    out = xee.diagnose_case(A, B, Cc, bc, r1=5e-3, r2=5e-3, max_iter=100000, alpha=1.0)["BAROTROPIC"]
+    assert int(out["iters"][0]) == 17900 and int(out["err"][0]) == 0
+    assert H.md5(out["psi"][0]) == "3495ddd52bcb05c39a5c6685f8f1f039"
+    assert H.md5(out["eta"][0]) == "a671b036d5e6f27fa1f9893076ae6e8a"
+
+
+def test_m_grid_md5_anchors():
+    """1024x512 fixed-work cases: 500 and 20,000 iterations."""
+    A, B, Cc, bc = H.test1_inputs(1024, 512)
+    assert H.md5(B) == "986b0fd66de089d7e32d3afc08bb53d0"
+    out = xee.diagnose_case(A, B, Cc, bc, r1=1e-8, r2=-1.0, max_iter=500, alpha=1.0)["BAROTROPIC"]
+    assert int(out["iters"][0]) == 500 and int(out["err"][0]) == 1
+    assert H.md5(out["psi"][0]) == "96ac915d5789a73fdd61a47447916235"
+    assert H.md5(out["eta"][0]) == "826fefae4b9f730278ab0cfbefcf4df9"
+    out = xee.diagnose_case(A, B, Cc, bc, r1=1e-8, r2=-1.0, max_iter=20000, alpha=1.0)["BAROTROPIC"]
+    assert H.md5(out["psi"][0]) == "f3c5da6719e63dbd39f59b82483ebc32"
+    assert H.md5(out["eta"][0]) == "327954effa6b33ee14590ba58a50dfce"
+
+
+def test_l_grid_md5_anchor():
+    """4096x2048, 100 iterations."""
+    A, B, Cc, bc = H.test1_inputs(4096, 2048)
+    assert H.md5(B) == "5d8a980b60a467c7438ba05cd92e1cc8"
+    out = xee.diagnose_case(A, B, Cc, bc, r1=1e-8, r2=-1.0, max_iter=100, alpha=1.0)["BAROTROPIC"]
+    assert H.md5(out["psi"][0]) == "1cc37e77edff7db54a4dc62430c0e201"
+    assert H.md5(out["eta"][0]) == "5690c1085e9714324340d4622341a62d"
+
+
+# ---- ensemble -----------------------------------------------------------------------------------
+
+def test_ensemble_members_equal_their_solo_runs():
+    """Batched members are bit-identical to the same case run alone and to the oracle; members that
+    converge at different iterations stop independently."""
+    nr, nz, M = 96, 64, 6
+    ins = [H.member_inputs(nr, nz, m) for m in range(M)]
+    A, B, Cc, bc = (np.stack([x[k] for x in ins]) for k in range(4))
+    cfg = dict(r1=2e-4, r2=5e-3, max_iter=20000, alpha=1.0)
+    out = xee.diagnose_case(A, B, Cc, bc, **cfg)["BAROTROPIC"]
+    iters = set()
+    for m in range(M):
+        want = H.diagnose_case(A[m], B[m], Cc[m], bc[m], **cfg)["BAROTROPIC"]
+        assert int(out["iters"][m]) == want["iters"], m
+        assert biteq(out["psi"][m], want["psi"]) and biteq(out["eta"][m], want["eta"]), m
+        assert out["r1"][m].tobytes() == want["r1"].tobytes()
+        iters.add(want["iters"])
+    assert len(iters) > 1, "members should stop at different iterations in this test"
+
+
+def test_ee_scalars_ensemble():
+    nr, nz, M = 64, 48, 3
+    ins = [H.member_inputs(nr, nz, m) for m in range(M)]
+    A, B, Cc, bc = (np.stack([x[k] for x in ins]) for k in range(4))
+    r = np.linspace(0, 1, nr - 1)[None, :]
+    z = np.linspace(0, 1, nz - 1)[:, None]
+    Q = np.stack([np.exp(-((r - 0.3) / 0.1) ** 2 - ((z - 0.5) / 0.2) ** 2) * (1 + 0.1 * m) for m in range(M)]).astype(np.float32)
+    cfg = dict(r1=1e-8, r2=-1.0, max_iter=300, alpha=1.0)
+    out = xee.diagnose_case(A, B, Cc, bc, Q=Q, **cfg)["BAROTROPIC"]
+    for m in range(M):
+        want = H.diagnose_case(A[m], B[m], Cc[m], bc[m], **cfg)
+        prof = want["profiles"]
+        sq = H.integrate_weight_B(Q[m], prof)
+        sqe = H.cal_sum_Qeta(Q[m], want["BAROTROPIC"]["eta"], prof)
+        assert out["sum_Q"][m].tobytes() == sq.tobytes()
+        assert out["sum_Qeta"][m].tobytes() == sqe.tobytes()
+        assert out["efficiency"][m].tobytes() == np.float32(sqe / sq).tobytes()

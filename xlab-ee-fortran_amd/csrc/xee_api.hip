@@ -1,0 +1,813 @@
+// xee_api.hip -- the C-ABI of libxee (include/xee.h): ensemble bookkeeping, the solve_elliptic
+// driver loop, and the Tier-1 drop-in entry points built on top of a one-member ensemble.
+// No CPU fallback anywhere: without a HIP device every compute entry returns XEE_ERR_NO_DEVICE.
+#include "../../include/xee.h"
+#include "xee_device.h"
+
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace xee;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                           \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(e_ == hipErrorNoDevice ? XEE_ERR_NO_DEVICE : XEE_ERR_HIP,              \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                    \
+    } while (0)
+
+#define XCHK(expr)                       \
+    do {                                 \
+        int s_ = (expr);                 \
+        if (s_ != XEE_OK) return s_;     \
+    } while (0)
+
+int require_device()
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(XEE_ERR_NO_DEVICE, "no HIP device visible (libxee has no CPU fallback)");
+    return XEE_OK;
+}
+
+bool g_setup_done = false;
+
+}  // namespace
+
+struct xee_ensemble {
+    Grid g{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int first_case_id = 0;
+    // per-member planes (members * plane floats each); optional ones are allocated on first use
+    float *A = nullptr, *B = nullptr, *C = nullptr, *bc = nullptr, *f = nullptr;
+    float* psi[2] = {nullptr, nullptr};
+    float *sA = nullptr, *sB = nullptr, *sC = nullptr, *coe = nullptr, *res = nullptr;
+    float *eta = nullptr, *u = nullptr, *w = nullptr, *Q = nullptr, *terms = nullptr;
+    int cur = 0;   // psi[cur] holds the solution of every member after a solve
+    // shared 1-D profiles
+    float *ra = nullptr, *za = nullptr, *rcuva = nullptr, *rho = nullptr, *exner = nullptr;
+    float dr = 0.f, dz = 0.f;
+    bool have_profiles = false;
+    MemberState* st = nullptr;
+    MemberState* st_host = nullptr;   // pinned
+    float* sums = nullptr;
+    float* sums_host = nullptr;       // pinned
+    std::vector<xee_case_record_t> rec;
+    xee_timing_t timing{};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+
+namespace {
+
+int alloc_planes(xee_ensemble* e, float** p, size_t nplanes = 1)
+{
+    if (*p) return XEE_OK;
+    const size_t bytes = e->g.plane * e->g.members * nplanes * sizeof(float);
+    hipError_t err = hipMalloc(reinterpret_cast<void**>(p), bytes);
+    if (err != hipSuccess) return fail(XEE_ERR_ALLOC, std::string("hipMalloc: ") + hipGetErrorString(err));
+    HIPCHK(hipMemsetAsync(*p, 0, bytes, e->stream));
+    return XEE_OK;
+}
+
+int use(xee_ensemble* e)
+{
+    if (!e) return fail(XEE_ERR_INVALID_ARGUMENT, "null ensemble");
+    HIPCHK(hipSetDevice(e->device));
+    return XEE_OK;
+}
+
+struct FieldRef { float** ptr; int n1, n2; size_t planes_off; };
+
+// field id -> device pointer (allocated on demand) and logical shape
+int field_ref(xee_ensemble* e, int field, float** base, int* n1, int* n2)
+{
+    const int nr = e->g.nx, nz = e->g.ny;
+    float** p = nullptr;
+    switch (field) {
+        case XEE_F_A: p = &e->A; *n1 = nr; *n2 = nz; break;
+        case XEE_F_B: p = &e->B; *n1 = nr; *n2 = nz; break;
+        case XEE_F_C: p = &e->C; *n1 = nr; *n2 = nz; break;
+        case XEE_F_BC_INIT: p = &e->bc; *n1 = nr; *n2 = nz; break;
+        case XEE_F_FORCING: p = &e->f; *n1 = nr; *n2 = nz; break;
+        case XEE_F_PSI: p = &e->psi[e->cur]; *n1 = nr; *n2 = nz; break;
+        case XEE_F_SOLVER_A: p = &e->sA; *n1 = nr - 1; *n2 = nz - 2; break;
+        case XEE_F_SOLVER_B: p = &e->sB; *n1 = nr - 1; *n2 = nz - 1; break;
+        case XEE_F_SOLVER_C: p = &e->sC; *n1 = nr - 2; *n2 = nz - 1; break;
+        case XEE_F_ETA: p = &e->eta; *n1 = nr - 1; *n2 = nz; break;
+        case XEE_F_U: p = &e->u; *n1 = nr; *n2 = nz - 1; break;
+        case XEE_F_W: p = &e->w; *n1 = nr - 1; *n2 = nz; break;
+        case XEE_F_Q: p = &e->Q; *n1 = nr - 1; *n2 = nz - 1; break;
+        case XEE_F_RESIDUAL: p = &e->res; *n1 = nr; *n2 = nz; break;
+        default:
+            if (field >= XEE_F_COE0 && field < XEE_F_COE0 + 9) {
+                XCHK(alloc_planes(e, &e->coe, 9));
+                *base = e->coe + (size_t)(field - XEE_F_COE0) * e->g.members * e->g.plane;
+                *n1 = nr; *n2 = nz;
+                return XEE_OK;
+            }
+            return fail(XEE_ERR_INVALID_ARGUMENT, "unknown field id");
+    }
+    XCHK(alloc_planes(e, p));
+    *base = *p;
+    return XEE_OK;
+}
+
+int check_launch(const char* what)
+{
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return fail(XEE_ERR_HIP, std::string(what) + ": " + hipGetErrorString(err));
+    return XEE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int xee_version(void) { return XEE_VERSION; }
+
+const char* xee_last_error(void) { return g_err.c_str(); }
+
+int xee_device_count(int* count)
+{
+    if (!count) return fail(XEE_ERR_INVALID_ARGUMENT, "null count");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *count = n;
+    return XEE_OK;
+}
+
+void xee_judge_error(int err)
+{
+    // xtt-lib-fortran/elliptic_tools.f90:333-358
+    bool known = false;
+    if (err == 0) { printf(" Elliptic Tools: Iteration success.\n"); known = true; }
+    if (err & XEE_ERRBIT_OVER_MAX_ITERATION) { printf(" Elliptic Tools: [Error] Max iteration reached.\n"); known = true; }
+    if (err & XEE_ERRBIT_EXPLODE) { printf(" Elliptic Tools: [Error] Iteration explodes.\n"); known = true; }
+    if (!known) printf(" Elliptic Tools: Unknown error code %d\n", err);
+    fflush(stdout);
+}
+
+// A13, src/diagnose/initialize-variables.f90:44-67 and read-input.f90:55-76 -- host arithmetic
+// (x86-64 baseline fp32, glibc powf/cosf/sinf), constants of xtt-lib-fortran/constants.f90:4-7.
+int xee_profiles(int geometry, int density_mode, const float* domain, int nr, int nz, float* ra, float* za,
+                 float* rcuva, float* exner, float* rho, float* sin_table, float* dr_out, float* dz_out)
+{
+    if (!domain || !ra || !za || !rcuva || !exner || !rho || !dr_out || !dz_out || nr < 2 || nz < 2)
+        return fail(XEE_ERR_INVALID_ARGUMENT, "xee_profiles: bad argument");
+    if (geometry != 0 && geometry != 1) return fail(XEE_ERR_INVALID_ARGUMENT, "geometry must be 0 or 1");
+    const float g0 = 9.8f, theta0 = 298.0f, Rd = 287.0f, p0 = 101300.0f;
+    const float Cv = 5.0f / 2.0f * Rd, Cp = Cv + Rd, kappa = Rd / Cp, h0 = Cp * theta0 / g0;
+    float Lr1, Lr2, Lz1, Lz2, planet_radius = 0.0f;
+    const float Lat1 = -90.0f, Lat2 = 90.0f;
+    if (geometry == 0) {
+        Lr1 = domain[0]; Lr2 = domain[1]; Lz1 = domain[2]; Lz2 = domain[3];
+    } else {
+        const float MATH_PI = acosf(-1.0f);                     // variables.f90:4
+        const float DEG2RAD = MATH_PI / 180.0f;
+        planet_radius = domain[0]; Lz1 = domain[1]; Lz2 = domain[2];
+        Lr1 = Lat1 * DEG2RAD * planet_radius;                   // read-input.f90:69-70
+        Lr2 = Lat2 * DEG2RAD * planet_radius;
+    }
+    const float dr = (Lr2 - Lr1) / (float)(nr - 1);
+    const float dz = (Lz2 - Lz1) / (float)(nz - 1);
+    for (int i = 0; i < nr; ++i) ra[i] = Lr1 + (float)i * dr;
+    const float expo = 1.0f / kappa - 1.0f, pref = p0 / (theta0 * Rd);
+    for (int j = 0; j < nz; ++j) {
+        za[j] = Lz1 + (float)j * dz;
+        if (density_mode == 0) { exner[j] = 1.0f - za[j] / h0; rho[j] = pref * powf(exner[j], expo); }
+        else { exner[j] = 1.0f; rho[j] = 1.0f; }
+    }
+    if (geometry == 0) {
+        for (int i = 0; i < nr; ++i) rcuva[i] = ra[i];
+    } else {
+        const float dlat = (Lat2 - Lat1) / (float)(nr - 1);
+        for (int i = 0; i < nr; ++i) {
+            const float lat = Lat1 + (float)i * dlat;
+            rcuva[i] = planet_radius * cosf(lat);
+            if (sin_table) sin_table[i] = sinf(lat);
+        }
+    }
+    *dr_out = dr;
+    *dz_out = dz;
+    return XEE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tier 2
+// ---------------------------------------------------------------------------------------------
+
+int xee_ensemble_create(xee_ensemble_t** out, int nr, int nz, int n_members, int device)
+{
+    if (!out) return fail(XEE_ERR_INVALID_ARGUMENT, "null out pointer");
+    *out = nullptr;
+    if (nr < 3 || nz < 3 || n_members < 1) return fail(XEE_ERR_INVALID_ARGUMENT, "need nr>=3, nz>=3, members>=1");
+    XCHK(require_device());
+    if (device < 0) HIPCHK(hipGetDevice(&device));
+    HIPCHK(hipSetDevice(device));
+    if (!g_setup_done) {
+        int s = sweep_kernel_setup();
+        if (s != 0) return fail(XEE_ERR_HIP, std::string("kernel setup: ") + hipGetErrorString((hipError_t)s));
+        g_setup_done = true;
+    }
+    xee_ensemble* e = new xee_ensemble();
+    e->device = device;
+    e->g.nx = nr;
+    e->g.ny = nz;
+    e->g.pitch = ((nr + 63) / 64) * 64;
+    e->g.members = n_members;
+    e->g.plane = (size_t)e->g.pitch * nz;
+    int st = XEE_OK;
+    auto guard = [&](int s) { if (st == XEE_OK) st = s; };
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return fail(XEE_ERR_HIP, "hipStreamCreate failed"); }
+    e->own_stream = true;
+    for (auto& ev : e->ev) if (hipEventCreate(&ev) != hipSuccess) guard(fail(XEE_ERR_HIP, "hipEventCreate failed"));
+    // planes every solve needs
+    guard(alloc_planes(e, &e->bc));
+    guard(alloc_planes(e, &e->f));
+    guard(alloc_planes(e, &e->psi[0]));
+    guard(alloc_planes(e, &e->psi[1]));
+    guard(alloc_planes(e, &e->coe, 9));
+    guard(alloc_planes(e, &e->res));
+    if (st == XEE_OK && hipMalloc(reinterpret_cast<void**>(&e->st), sizeof(MemberState) * n_members) != hipSuccess) guard(fail(XEE_ERR_ALLOC, "hipMalloc state"));
+    if (st == XEE_OK && hipMalloc(reinterpret_cast<void**>(&e->sums), sizeof(float) * n_members) != hipSuccess) guard(fail(XEE_ERR_ALLOC, "hipMalloc sums"));
+    if (st == XEE_OK && hipHostMalloc(reinterpret_cast<void**>(&e->st_host), sizeof(MemberState) * n_members) != hipSuccess) guard(fail(XEE_ERR_ALLOC, "hipHostMalloc state"));
+    if (st == XEE_OK && hipHostMalloc(reinterpret_cast<void**>(&e->sums_host), sizeof(float) * n_members) != hipSuccess) guard(fail(XEE_ERR_ALLOC, "hipHostMalloc sums"));
+    const size_t nv = (size_t)(nr > nz ? nr : nz) + 64;
+    for (float** v : {&e->ra, &e->za, &e->rcuva, &e->rho, &e->exner})
+        if (st == XEE_OK && hipMalloc(reinterpret_cast<void**>(v), nv * sizeof(float)) != hipSuccess) guard(fail(XEE_ERR_ALLOC, "hipMalloc profile"));
+    if (st != XEE_OK) { xee_ensemble_destroy(e); return st; }
+    launch_state_init(e->g, e->st, e->stream);
+    e->rec.assign(n_members, xee_case_record_t{});
+    for (int m = 0; m < n_members; ++m) e->rec[m].case_id = m;
+    if (hipStreamSynchronize(e->stream) != hipSuccess) { xee_ensemble_destroy(e); return fail(XEE_ERR_HIP, "ensemble init failed"); }
+    *out = e;
+    return XEE_OK;
+}
+
+int xee_ensemble_destroy(xee_ensemble_t* e)
+{
+    if (!e) return XEE_OK;
+    hipSetDevice(e->device);
+    if (e->stream) hipStreamSynchronize(e->stream);
+    for (float* p : {e->A, e->B, e->C, e->bc, e->f, e->psi[0], e->psi[1], e->sA, e->sB, e->sC, e->coe, e->res,
+                     e->eta, e->u, e->w, e->Q, e->terms, e->ra, e->za, e->rcuva, e->rho, e->exner, e->sums})
+        if (p) hipFree(p);
+    if (e->st) hipFree(e->st);
+    if (e->st_host) hipHostFree(e->st_host);
+    if (e->sums_host) hipHostFree(e->sums_host);
+    for (auto& ev : e->ev) if (ev) hipEventDestroy(ev);
+    if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
+    delete e;
+    return XEE_OK;
+}
+
+int xee_ensemble_set_stream(xee_ensemble_t* e, void* hip_stream)
+{
+    XCHK(use(e));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->own_stream && e->stream) { hipStreamDestroy(e->stream); e->own_stream = false; }
+    if (hip_stream) {
+        e->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    } else {
+        HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        e->own_stream = true;
+    }
+    return XEE_OK;
+}
+
+int xee_ensemble_set_case_ids(xee_ensemble_t* e, int first_case_id)
+{
+    if (!e) return fail(XEE_ERR_INVALID_ARGUMENT, "null ensemble");
+    e->first_case_id = first_case_id;
+    for (int m = 0; m < e->g.members; ++m) e->rec[m].case_id = first_case_id + m;
+    return XEE_OK;
+}
+
+int xee_ensemble_set_profiles(xee_ensemble_t* e, const float* ra, const float* za, const float* rcuva,
+                              const float* rho, const float* exner, float dr, float dz)
+{
+    XCHK(use(e));
+    if (!ra || !za || !rcuva || !rho || !exner) return fail(XEE_ERR_INVALID_ARGUMENT, "null profile");
+    const size_t br = sizeof(float) * e->g.nx, bz = sizeof(float) * e->g.ny;
+    HIPCHK(hipMemcpyAsync(e->ra, ra, br, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->rcuva, rcuva, br, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->za, za, bz, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->rho, rho, bz, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->exner, exner, bz, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->dr = dr;
+    e->dz = dz;
+    e->have_profiles = true;
+    return XEE_OK;
+}
+
+static int xfer(xee_ensemble_t* e, int field, int first, int count, float* host, bool up)
+{
+    XCHK(use(e));
+    if (!host || first < 0 || count < 1 || first + count > e->g.members)
+        return fail(XEE_ERR_INVALID_ARGUMENT, "bad member range or null host pointer");
+    float* base = nullptr;
+    int n1 = 0, n2 = 0;
+    XCHK(field_ref(e, field, &base, &n1, &n2));
+    for (int k = 0; k < count; ++k) {
+        float* d = base + (size_t)(first + k) * e->g.plane;
+        float* h = host + (size_t)k * n1 * n2;
+        if (up)
+            HIPCHK(hipMemcpy2DAsync(d, sizeof(float) * e->g.pitch, h, sizeof(float) * n1, sizeof(float) * n1, n2, hipMemcpyHostToDevice, e->stream));
+        else
+            HIPCHK(hipMemcpy2DAsync(h, sizeof(float) * n1, d, sizeof(float) * e->g.pitch, sizeof(float) * n1, n2, hipMemcpyDeviceToHost, e->stream));
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return XEE_OK;
+}
+
+int xee_ensemble_upload(xee_ensemble_t* e, int field, int first, int count, const float* host)
+{
+    return xfer(e, field, first, count, const_cast<float*>(host), true);
+}
+
+int xee_ensemble_download(xee_ensemble_t* e, int field, int first, int count, float* host)
+{
+    return xfer(e, field, first, count, host, false);
+}
+
+int xee_ensemble_device_plane(xee_ensemble_t* e, int field, void** dptr, int* pitch, size_t* member_stride,
+                              int* n1, int* n2)
+{
+    XCHK(use(e));
+    float* base = nullptr;
+    int a = 0, b = 0;
+    XCHK(field_ref(e, field, &base, &a, &b));
+    HIPCHK(hipStreamSynchronize(e->stream));   // the zero-fill of a fresh plane has landed
+    if (dptr) *dptr = base;
+    if (pitch) *pitch = e->g.pitch;
+    if (member_stride) *member_stride = e->g.plane;
+    if (n1) *n1 = a;
+    if (n2) *n2 = b;
+    return XEE_OK;
+}
+
+int xee_ensemble_forcing_from_B(xee_ensemble_t* e)
+{
+    XCHK(use(e));
+    if (!e->B) return fail(XEE_ERR_INVALID_ARGUMENT, "B has not been uploaded");
+    launch_negate(e->g, e->B, e->f, e->stream);
+    return check_launch("negate");
+}
+
+int xee_ensemble_assemble(xee_ensemble_t* e, int variant)
+{
+    XCHK(use(e));
+    if (!e->have_profiles) return fail(XEE_ERR_INVALID_ARGUMENT, "profiles not set");
+    if (!e->A || !e->B || !e->C) return fail(XEE_ERR_INVALID_ARGUMENT, "A, B, C must be uploaded first");
+    if (variant != XEE_BAROTROPIC && variant != XEE_BAROCLINIC) return fail(XEE_ERR_INVALID_ARGUMENT, "bad variant");
+    XCHK(alloc_planes(e, &e->sA));
+    XCHK(alloc_planes(e, &e->sB));
+    XCHK(alloc_planes(e, &e->sC));
+    launch_solver_coef(e->g, e->A, e->B, e->C, e->rcuva, e->rho, e->sA, e->sB, e->sC, e->stream);
+    launch_cal_coe(e->g, e->sA, variant == XEE_BAROCLINIC ? e->sB : nullptr, e->sC, e->coe, e->dr, e->dz, e->stream);
+    return check_launch("assemble");
+}
+
+// solve_elliptic, xtt-lib-fortran/elliptic_tools.f90:93-265, for every member at once.
+int xee_ensemble_solve(xee_ensemble_t* e, int max_iter, int check_step, int converge_time, int lost_rate,
+                       float r1, float r2, float alpha, int flags)
+{
+    XCHK(use(e));
+    // :112-129
+    const bool chk_abs = r1 > 0.0f, chk_rel = r2 > 0.0f;
+    if (!chk_abs && !chk_rel)
+        return fail(XEE_ERR_INVALID_CRITERIA, "[check_abs_err] and [check_rel_err] cannot both be non-positive.");
+    if (max_iter < 0) return fail(XEE_ERR_INVALID_ARGUMENT, "max_iter < 0");
+    ConvParams cp{};
+    cp.r1 = chk_abs ? r1 : FLT_MAX;
+    cp.r2 = chk_rel ? r2 : FLT_MAX;
+    const int cs = check_step > 0 ? check_step : 100;          // :131-144
+    cp.converge_time = converge_time > 0 ? converge_time : 10;
+    cp.lost_rate = lost_rate > 0 ? lost_rate : 5;
+    cp.n_interior = (e->g.nx - 2) * (e->g.ny - 2);
+    cp.debug = (flags & XEE_SOLVE_TRACE) ? 2 : 0;
+    const Grid& g = e->g;
+    hipStream_t s = e->stream;
+
+    // :171-174  workspace = dat; the first iteration reads dat.  Both ping-pong planes carry the rim.
+    if (flags & XEE_SOLVE_KEEP_PSI) launch_copy2(g, e->psi[e->cur], e->psi[e->cur ^ 1], nullptr, s);
+    else { launch_copy2(g, e->bc, e->psi[0], e->psi[1], s); e->cur = 0; }
+    launch_state_init(g, e->st, s);
+    const int start = e->cur;
+
+    e->timing = xee_timing_t{};
+    HIPCHK(hipEventRecord(e->ev[0], s));
+    bool block_open = false;
+    int cnt = 0;
+    bool all_done = (max_iter == 0);
+    for (cnt = 1; cnt <= max_iter && !all_done; ++cnt) {
+        const bool check = (cnt % cs) == 0;
+        if (!block_open) { HIPCHK(hipEventRecord(e->ev[2], s)); block_open = true; }
+        const int src = (start + cnt - 1) & 1;
+        launch_sweep(g, e->psi[src], e->psi[src ^ 1], e->coe, e->f, check ? e->res : nullptr, e->st, alpha, s);
+        e->timing.sweep_launches += 1;
+        e->timing.iterations += 1;
+        const bool last = cnt == max_iter;
+        if (check) {
+            HIPCHK(hipEventRecord(e->ev[3], s));
+            launch_seqsum(g, e->res, 1, g.nx - 1, 1, g.ny - 1, true, e->sums, e->st, s);
+            cp.cnt = cnt;
+            cp.is_last = last ? 1 : 0;
+            launch_conv_update(g, e->sums, e->st, cp, s);
+            e->timing.check_launches += 1;
+        } else if (last) {
+            launch_finalize(g, e->st, max_iter, s);
+        }
+        if (check || last) {
+            XCHK(check_launch("sweep/check"));
+            HIPCHK(hipMemcpyAsync(e->st_host, e->st, sizeof(MemberState) * g.members, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            if (check) {
+                float ms = 0.f;
+                HIPCHK(hipEventElapsedTime(&ms, e->ev[2], e->ev[3]));
+                e->timing.sweep_ms += ms;
+                block_open = false;
+            }
+            all_done = true;
+            for (int m = 0; m < g.members; ++m) if (e->st_host[m].active) { all_done = false; break; }
+        }
+    }
+    HIPCHK(hipEventRecord(e->ev[1], s));
+    if (max_iter == 0) {
+        HIPCHK(hipMemcpyAsync(e->st_host, e->st, sizeof(MemberState) * g.members, hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e->ev[0], e->ev[1]));
+    e->timing.solve_ms = ms;
+
+    // :259-264  every member's result into one plane.  Iteration k wrote psi[(start+k)&1]; the
+    // planes of a stopped member are never touched again.
+    int last_iter = 0;
+    for (int m = 0; m < g.members; ++m) if (e->st_host[m].iters > last_iter) last_iter = e->st_host[m].iters;
+    const int fin = (start + last_iter) & 1;
+    for (int m = 0; m < g.members; ++m) {
+        const int mine = (start + e->st_host[m].iters) & 1;
+        if (mine != fin)
+            HIPCHK(hipMemcpyAsync(e->psi[fin] + (size_t)m * g.plane, e->psi[mine] + (size_t)m * g.plane,
+                                  sizeof(float) * g.plane, hipMemcpyDeviceToDevice, s));
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    e->cur = fin;
+    for (int m = 0; m < g.members; ++m) {
+        xee_case_record_t& r = e->rec[m];
+        r.iters = e->st_host[m].iters;
+        r.err_bits = e->st_host[m].err_bits;
+        r.err_now = e->st_host[m].err_now;
+        r.ratio = e->st_host[m].ratio;
+    }
+    return XEE_OK;
+}
+
+int xee_ensemble_cal_eta(xee_ensemble_t* e)
+{
+    XCHK(use(e));
+    if (!e->have_profiles) return fail(XEE_ERR_INVALID_ARGUMENT, "profiles not set");
+    XCHK(alloc_planes(e, &e->eta));
+    launch_cal_eta(e->g, e->psi[e->cur], e->eta, e->ra, e->rcuva, e->rho, e->exner, e->stream);
+    return check_launch("cal_eta");
+}
+
+int xee_ensemble_cal_uw(xee_ensemble_t* e)
+{
+    XCHK(use(e));
+    if (!e->have_profiles) return fail(XEE_ERR_INVALID_ARGUMENT, "profiles not set");
+    XCHK(alloc_planes(e, &e->u));
+    XCHK(alloc_planes(e, &e->w));
+    launch_cal_uw(e->g, e->psi[e->cur], e->u, e->w, e->ra, e->za, e->rcuva, e->rho, e->stream);
+    return check_launch("cal_uw");
+}
+
+int xee_ensemble_ee_scalars(xee_ensemble_t* e)
+{
+    XCHK(use(e));
+    if (!e->have_profiles) return fail(XEE_ERR_INVALID_ARGUMENT, "profiles not set");
+    if (!e->Q || !e->eta) return fail(XEE_ERR_INVALID_ARGUMENT, "Q must be uploaded and eta computed first");
+    XCHK(alloc_planes(e, &e->terms));
+    const Grid& g = e->g;
+    hipStream_t s = e->stream;
+    std::vector<float> sq(g.members);
+    launch_terms_weight(g, e->Q, e->terms, e->ra, e->za, e->rcuva, e->rho, s);
+    launch_seqsum(g, e->terms, 0, g.nx - 1, 0, g.ny - 1, false, e->sums, nullptr, s);
+    HIPCHK(hipMemcpyAsync(e->sums_host, e->sums, sizeof(float) * g.members, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (int m = 0; m < g.members; ++m) sq[m] = e->sums_host[m];
+    launch_terms_Qeta(g, e->Q, e->eta, e->terms, e->ra, e->za, e->rcuva, e->rho, s);
+    launch_seqsum(g, e->terms, 0, g.nx - 1, 0, g.ny - 1, false, e->sums, nullptr, s);
+    HIPCHK(hipMemcpyAsync(e->sums_host, e->sums, sizeof(float) * g.members, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    XCHK(check_launch("ee_scalars"));
+    for (int m = 0; m < g.members; ++m) {
+        e->rec[m].sum_Q = sq[m];
+        e->rec[m].sum_Qeta = e->sums_host[m];
+        e->rec[m].efficiency = e->sums_host[m] / sq[m];      // old-diagnose/diagnose.f90:792-793
+    }
+    return XEE_OK;
+}
+
+int xee_ensemble_records(xee_ensemble_t* e, xee_case_record_t* out)
+{
+    if (!e || !out) return fail(XEE_ERR_INVALID_ARGUMENT, "null argument");
+    memcpy(out, e->rec.data(), sizeof(xee_case_record_t) * e->g.members);
+    return XEE_OK;
+}
+
+int xee_ensemble_timing(xee_ensemble_t* e, xee_timing_t* out)
+{
+    if (!e || !out) return fail(XEE_ERR_INVALID_ARGUMENT, "null argument");
+    *out = e->timing;
+    return XEE_OK;
+}
+
+int xee_ensemble_time_sweeps(xee_ensemble_t* e, int iters, int variant, float alpha, double* elapsed_ms,
+                             int64_t* launches)
+{
+    XCHK(use(e));
+    if (iters < 1 || variant != 0) return fail(XEE_ERR_INVALID_ARGUMENT, "iters >= 1 and variant 0 (streaming) only");
+    const Grid& g = e->g;
+    hipStream_t s = e->stream;
+    launch_state_init(g, e->st, s);
+    HIPCHK(hipEventRecord(e->ev[0], s));
+    for (int k = 0; k < iters; ++k) {
+        const int src = (e->cur + k) & 1;
+        launch_sweep(g, e->psi[src], e->psi[src ^ 1], e->coe, e->f, nullptr, e->st, alpha, s);
+    }
+    HIPCHK(hipEventRecord(e->ev[1], s));
+    HIPCHK(hipStreamSynchronize(s));
+    XCHK(check_launch("time_sweeps"));
+    e->cur = (e->cur + iters) & 1;
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e->ev[0], e->ev[1]));
+    if (elapsed_ms) *elapsed_ms = ms;
+    if (launches) *launches = iters;
+    return XEE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tier 1: host arrays in, host arrays out, through a one-member ensemble
+// ---------------------------------------------------------------------------------------------
+
+namespace {
+struct Scoped {
+    xee_ensemble_t* e = nullptr;
+    ~Scoped() { if (e) xee_ensemble_destroy(e); }
+};
+}  // namespace
+
+int xee_cal_coe(const float* a, const float* b, const float* c, float* coe, float dx, float dy, int nx, int ny, int* err)
+{
+    if (!a || !b || !c || !coe || !err) return fail(XEE_ERR_INVALID_ARGUMENT, "null argument");
+    *err = 1;                                                   // elliptic_tools.f90:33
+    Scoped sc;
+    XCHK(xee_ensemble_create(&sc.e, nx, ny, 1, -1));
+    xee_ensemble_t* e = sc.e;
+    XCHK(xee_ensemble_upload(e, XEE_F_SOLVER_A, 0, 1, a));
+    XCHK(xee_ensemble_upload(e, XEE_F_SOLVER_B, 0, 1, b));
+    XCHK(xee_ensemble_upload(e, XEE_F_SOLVER_C, 0, 1, c));
+    launch_cal_coe(e->g, e->sA, e->sB, e->sC, e->coe, dx, dy, e->stream);
+    float* aos = nullptr;
+    const size_t bytes = sizeof(float) * 9 * (size_t)nx * ny;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&aos), bytes));
+    // only interior entries are written (the reference leaves the rim untouched): start from the caller's bytes
+    hipError_t he = hipMemcpyAsync(aos, coe, bytes, hipMemcpyHostToDevice, e->stream);
+    if (he == hipSuccess) { launch_coe_soa_to_aos(e->g, e->coe, aos, e->stream); he = hipMemcpyAsync(coe, aos, bytes, hipMemcpyDeviceToHost, e->stream); }
+    if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+    if (he == hipSuccess) he = hipGetLastError();
+    hipFree(aos);
+    if (he != hipSuccess) return fail(XEE_ERR_HIP, std::string("xee_cal_coe: ") + hipGetErrorString(he));
+    *err = 0;                                                   // :58
+    return XEE_OK;
+}
+
+static int upload_coe_aos(xee_ensemble_t* e, const float* coe)
+{
+    float* aos = nullptr;
+    const size_t bytes = sizeof(float) * 9 * (size_t)e->g.nx * e->g.ny;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&aos), bytes));
+    hipError_t he = hipMemcpyAsync(aos, coe, bytes, hipMemcpyHostToDevice, e->stream);
+    if (he == hipSuccess) { launch_coe_aos_to_soa(e->g, aos, e->coe, e->stream); he = hipStreamSynchronize(e->stream); }
+    if (he == hipSuccess) he = hipGetLastError();
+    hipFree(aos);
+    if (he != hipSuccess) return fail(XEE_ERR_HIP, std::string("coe upload: ") + hipGetErrorString(he));
+    return XEE_OK;
+}
+
+int xee_do_elliptic(const float* psi, const float* coe, float* outdat, int nx, int ny, int* err)
+{
+    if (!psi || !coe || !outdat || !err) return fail(XEE_ERR_INVALID_ARGUMENT, "null argument");
+    Scoped sc;
+    XCHK(xee_ensemble_create(&sc.e, nx, ny, 1, -1));
+    xee_ensemble_t* e = sc.e;
+    XCHK(upload_coe_aos(e, coe));
+    XCHK(xee_ensemble_upload(e, XEE_F_BC_INIT, 0, 1, psi));
+    // interior only: seed the output plane with the caller's outdat so its rim survives
+    XCHK(xee_ensemble_upload(e, XEE_F_RESIDUAL, 0, 1, outdat));
+    launch_apply(e->g, e->bc, e->coe, e->res, e->stream);
+    XCHK(check_launch("apply"));
+    XCHK(xee_ensemble_download(e, XEE_F_RESIDUAL, 0, 1, outdat));
+    *err = 1;                                                   // elliptic_tools.f90:73 (never cleared)
+    return XEE_OK;
+}
+
+int xee_solve_elliptic(int* max_iter, int check_step, int converge_time, int lost_rate, float* strategy_r1,
+                       float* strategy_r2, float alpha, float* dat, const float* coe, const float* f,
+                       float* workspace, int nx, int ny, int* err, int debug)
+{
+    if (!max_iter || !strategy_r1 || !strategy_r2 || !dat || !coe || !f || !err)
+        return fail(XEE_ERR_INVALID_ARGUMENT, "null argument");
+    (void)workspace;   // scratch in the reference; the device keeps its own ping-pong plane
+    if (!(*strategy_r1 > 0.0f) && !(*strategy_r2 > 0.0f)) {
+        printf(" ERROR: [check_abs_err] and [check_rel_err] cannot both be non-positive.\n");
+        return fail(XEE_ERR_INVALID_CRITERIA, "both criteria non-positive");
+    }
+    if (debug == 1 || debug == 2) {                             // :146-158
+        printf(" ----- Solve Elliptic Inputs -----\n");
+        printf("   max_iter       :  %d\n", *max_iter);
+        printf("   strategy_r1    :  %.8G\n", *strategy_r1 > 0.0f ? *strategy_r1 : FLT_MAX);
+        printf("   strategy_r2    :  %.8G\n", *strategy_r2 > 0.0f ? *strategy_r2 : FLT_MAX);
+        printf("   alpha          :  %.8G\n", alpha);
+        printf("   (nx, ny)       : ( %d ,  %d )\n", nx, ny);
+        printf("   debug          :  %d\n", debug);
+        printf("   check step     :  %d\n", check_step > 0 ? check_step : 100);
+        printf("   converge time :  %d\n", converge_time > 0 ? converge_time : 10);
+        printf(" ---------------------------------\n");
+    }
+    Scoped sc;
+    XCHK(xee_ensemble_create(&sc.e, nx, ny, 1, -1));
+    xee_ensemble_t* e = sc.e;
+    XCHK(upload_coe_aos(e, coe));
+    XCHK(xee_ensemble_upload(e, XEE_F_BC_INIT, 0, 1, dat));
+    XCHK(xee_ensemble_upload(e, XEE_F_FORCING, 0, 1, f));
+    XCHK(xee_ensemble_solve(e, *max_iter, check_step, converge_time, lost_rate, *strategy_r1, *strategy_r2, alpha,
+                            debug == 2 ? XEE_SOLVE_TRACE : XEE_SOLVE_DEFAULT));
+    XCHK(xee_ensemble_download(e, XEE_F_PSI, 0, 1, dat));
+    const xee_case_record_t& r = e->rec[0];
+    *err = r.err_bits;
+    if (*max_iter > 0) {                                        // :253 (only reached when the loop ran)
+        *max_iter = r.iters;
+        *strategy_r1 = r.err_now;
+        *strategy_r2 = r.ratio;
+        xee_judge_error(*err);                                  // :254
+    }
+    return XEE_OK;
+}
+
+int xee_solver_coefficients(const float* rhoA, const float* rhoB, const float* rhoC, const float* rcuva,
+                            const float* rho, float* solverA, float* solverB, float* solverC, int nr, int nz)
+{
+    if (!rhoA || !rhoB || !rhoC || !rcuva || !rho || !solverA || !solverB || !solverC)
+        return fail(XEE_ERR_INVALID_ARGUMENT, "null argument");
+    Scoped sc;
+    XCHK(xee_ensemble_create(&sc.e, nr, nz, 1, -1));
+    xee_ensemble_t* e = sc.e;
+    std::vector<float> zr(nr, 0.f), zz(nz, 0.f);
+    XCHK(xee_ensemble_set_profiles(e, zr.data(), zz.data(), rcuva, rho, zz.data(), 0.f, 0.f));
+    XCHK(xee_ensemble_upload(e, XEE_F_A, 0, 1, rhoA));
+    XCHK(xee_ensemble_upload(e, XEE_F_B, 0, 1, rhoB));
+    XCHK(xee_ensemble_upload(e, XEE_F_C, 0, 1, rhoC));
+    XCHK(alloc_planes(e, &e->sA));
+    XCHK(alloc_planes(e, &e->sB));
+    XCHK(alloc_planes(e, &e->sC));
+    launch_solver_coef(e->g, e->A, e->B, e->C, e->rcuva, e->rho, e->sA, e->sB, e->sC, e->stream);
+    XCHK(check_launch("solver_coef"));
+    XCHK(xee_ensemble_download(e, XEE_F_SOLVER_A, 0, 1, solverA));
+    XCHK(xee_ensemble_download(e, XEE_F_SOLVER_B, 0, 1, solverB));
+    XCHK(xee_ensemble_download(e, XEE_F_SOLVER_C, 0, 1, solverC));
+    return XEE_OK;
+}
+
+int xee_cal_eta(const float* rchi, float* eta, const float* ra, const float* rcuva, const float* rho,
+                const float* exner, int nr, int nz)
+{
+    if (!rchi || !eta || !ra || !rcuva || !rho || !exner) return fail(XEE_ERR_INVALID_ARGUMENT, "null argument");
+    Scoped sc;
+    XCHK(xee_ensemble_create(&sc.e, nr, nz, 1, -1));
+    xee_ensemble_t* e = sc.e;
+    std::vector<float> zz(nz, 0.f);
+    XCHK(xee_ensemble_set_profiles(e, ra, zz.data(), rcuva, rho, exner, 0.f, 0.f));
+    XCHK(xee_ensemble_upload(e, XEE_F_PSI, 0, 1, rchi));
+    XCHK(xee_ensemble_cal_eta(e));
+    return xee_ensemble_download(e, XEE_F_ETA, 0, 1, eta);
+}
+
+int xee_cal_uw(const float* rpsi, float* u, float* w, const float* ra, const float* za, const float* rcuva,
+               const float* rho, int nr, int nz)
+{
+    if (!rpsi || !u || !w || !ra || !za || !rcuva || !rho) return fail(XEE_ERR_INVALID_ARGUMENT, "null argument");
+    Scoped sc;
+    XCHK(xee_ensemble_create(&sc.e, nr, nz, 1, -1));
+    xee_ensemble_t* e = sc.e;
+    XCHK(xee_ensemble_set_profiles(e, ra, za, rcuva, rho, rho, 0.f, 0.f));
+    XCHK(xee_ensemble_upload(e, XEE_F_PSI, 0, 1, rpsi));
+    XCHK(xee_ensemble_cal_uw(e));
+    XCHK(xee_ensemble_download(e, XEE_F_U, 0, 1, u));
+    return xee_ensemble_download(e, XEE_F_W, 0, 1, w);
+}
+
+static int integrate_common(const float* wgt, const float* eta, const float* ra, const float* za,
+                            const float* rcuva, const float* rho, int nr, int nz, float* sum)
+{
+    if (!wgt || !ra || !za || !rcuva || !rho || !sum) return fail(XEE_ERR_INVALID_ARGUMENT, "null argument");
+    Scoped sc;
+    XCHK(xee_ensemble_create(&sc.e, nr, nz, 1, -1));
+    xee_ensemble_t* e = sc.e;
+    XCHK(xee_ensemble_set_profiles(e, ra, za, rcuva, rho, rho, 0.f, 0.f));
+    XCHK(xee_ensemble_upload(e, XEE_F_Q, 0, 1, wgt));
+    XCHK(alloc_planes(e, &e->terms));
+    if (eta) {
+        XCHK(xee_ensemble_upload(e, XEE_F_ETA, 0, 1, eta));
+        launch_terms_Qeta(e->g, e->Q, e->eta, e->terms, e->ra, e->za, e->rcuva, e->rho, e->stream);
+    } else {
+        launch_terms_weight(e->g, e->Q, e->terms, e->ra, e->za, e->rcuva, e->rho, e->stream);
+    }
+    launch_seqsum(e->g, e->terms, 0, nr - 1, 0, nz - 1, false, e->sums, nullptr, e->stream);
+    XCHK(check_launch("integrate"));
+    HIPCHK(hipMemcpyAsync(e->sums_host, e->sums, sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    *sum = e->sums_host[0];
+    return XEE_OK;
+}
+
+int xee_integrate_weight_B(const float* weight, const float* ra, const float* za, const float* rcuva,
+                           const float* rho, int nr, int nz, float* sum)
+{
+    return integrate_common(weight, nullptr, ra, za, rcuva, rho, nr, nz, sum);
+}
+
+int xee_cal_sum_Qeta(const float* Q, const float* eta, const float* ra, const float* za, const float* rcuva,
+                     const float* rho, int nr, int nz, float* sum)
+{
+    if (!eta) return fail(XEE_ERR_INVALID_ARGUMENT, "null eta");
+    return integrate_common(Q, eta, ra, za, rcuva, rho, nr, nz, sum);
+}
+
+int xee_cal_wtheta(const float* w_A, const float* theta_B, float* wtheta_B, int nr, int nz)
+{
+    if (!w_A || !theta_B || !wtheta_B) return fail(XEE_ERR_INVALID_ARGUMENT, "null argument");
+    Scoped sc;
+    XCHK(xee_ensemble_create(&sc.e, nr, nz, 1, -1));
+    xee_ensemble_t* e = sc.e;
+    XCHK(xee_ensemble_upload(e, XEE_F_W, 0, 1, w_A));
+    XCHK(xee_ensemble_upload(e, XEE_F_Q, 0, 1, theta_B));
+    XCHK(alloc_planes(e, &e->terms));
+    launch_wtheta(e->g, e->w, e->Q, e->terms, e->stream);
+    XCHK(check_launch("wtheta"));
+    float* keep = e->Q;           // download the (nr-1,nz-1) result through the Q field's shape
+    e->Q = e->terms;
+    int st = xee_ensemble_download(e, XEE_F_Q, 0, 1, wtheta_B);
+    e->Q = keep;
+    return st;
+}
+
+int xee_rhs_thermal(const float* Q_B, const float* ra, const float* exner, float* rhs_O, int nr, int nz)
+{
+    if (!Q_B || !ra || !exner || !rhs_O) return fail(XEE_ERR_INVALID_ARGUMENT, "null argument");
+    Scoped sc;
+    XCHK(xee_ensemble_create(&sc.e, nr, nz, 1, -1));
+    xee_ensemble_t* e = sc.e;
+    std::vector<float> zz(nz, 0.f);
+    XCHK(xee_ensemble_set_profiles(e, ra, zz.data(), ra, zz.data(), exner, 0.f, 0.f));
+    XCHK(xee_ensemble_upload(e, XEE_F_Q, 0, 1, Q_B));
+    XCHK(alloc_planes(e, &e->terms));
+    launch_rhs_thermal(e->g, e->Q, e->ra, e->exner, e->terms, e->f, e->stream);
+    XCHK(check_launch("rhs_thermal"));
+    return xee_ensemble_download(e, XEE_F_FORCING, 0, 1, rhs_O);
+}
+
+int xee_rhs_from_B(const float* b_B, float* f_O, int nr, int nz)
+{
+    if (!b_B || !f_O) return fail(XEE_ERR_INVALID_ARGUMENT, "null argument");
+    Scoped sc;
+    XCHK(xee_ensemble_create(&sc.e, nr, nz, 1, -1));
+    xee_ensemble_t* e = sc.e;
+    XCHK(xee_ensemble_upload(e, XEE_F_Q, 0, 1, b_B));
+    launch_rhs_from_B(e->g, e->Q, e->f, e->stream);
+    XCHK(check_launch("rhs_from_B"));
+    return xee_ensemble_download(e, XEE_F_FORCING, 0, 1, f_O);
+}
+
+}  // extern "C"

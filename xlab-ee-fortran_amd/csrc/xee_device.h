@@ -1,0 +1,85 @@
+// xee_device.h -- internal types shared by the HIP kernels and the C-ABI layer of libxee.
+//
+// Device data layout (see DESIGN.md "Data layout in HBM"):
+//   every 2-D field of one ensemble member is a *plane* of ny rows x pitch floats, r (i) contiguous,
+//   pitch = nx rounded up to 64 floats (256-byte rows, every row 16-byte aligned for dwordx4 access);
+//   member m of a field lives at base + m*plane (plane = pitch*ny floats); the nine stencil
+//   coefficients are nine such fields (SoA), coefficient k of member m at coe + (k*members+m)*plane.
+//   The reference's AoS coe(9,nx,ny) (xtt-lib-fortran/elliptic_tools.f90:12) only exists at the
+//   Tier-1 host boundary.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace xee {
+
+struct Grid {
+    int nx, ny;      // logical O-grid extents (nr, nz)
+    int pitch;       // floats per row, multiple of 64
+    int members;     // ensemble members resident on this device
+    size_t plane;    // floats per member per field = pitch * ny
+};
+
+// per-member solver state, owned by the device between checks
+// (the locals of solve_elliptic, xtt-lib-fortran/elliptic_tools.f90:102-109,160-164)
+struct MemberState {
+    int active;        // 1 while the member still iterates
+    int iters;         // iterations used (max_iter on return, :253)
+    int err_bits;      // :244
+    int converge_cnt;  // :160
+    int lose_cnt;      // :161
+    float err_before;  // :163
+    float err_now;     // strategy_r1 on return
+    float ratio;       // strategy_r2 on return
+};
+
+struct ConvParams {
+    float r1, r2;          // after the <=0 -> HUGE substitution (:112-124)
+    int converge_time;     // :136-139
+    int lost_rate;         // :141-144
+    int cnt;               // iteration number of this check
+    int is_last;           // cnt == max_iter (:242-248)
+    int n_interior;        // (nx-2)*(ny-2), integer product converted to real (:199)
+    int debug;             // 2: per-check trace (:202-204)
+};
+
+// ---- launch wrappers (xee_kernels.hip) ------------------------------------------------------
+void launch_solver_coef(const Grid& g, const float* A, const float* B, const float* C,
+                        const float* rcuva, const float* rho, float* sA, float* sB, float* sC,
+                        hipStream_t s);
+void launch_cal_coe(const Grid& g, const float* sA, const float* sB /* nullptr: B = 0 */,
+                    const float* sC, float* coe, float dx, float dy, hipStream_t s);
+void launch_apply(const Grid& g, const float* psi, const float* coe, float* out, hipStream_t s);
+// one damped-Jacobi iteration (streaming kernel): psi_out = psi_in + alpha*R/(-c5), R optional
+void launch_sweep(const Grid& g, const float* psi_in, float* psi_out, const float* coe,
+                  const float* f, float* res /* nullptr: not written */, const MemberState* st,
+                  float alpha, hipStream_t s);
+// sequential fp32 sum, reference loop order (i outer, j inner), of T or T*T over a sub-rectangle
+void launch_seqsum(const Grid& g, const float* T, int i0, int i1, int j0, int j1, bool square,
+                   float* out_sums, const MemberState* st, hipStream_t s);
+void launch_conv_update(const Grid& g, const float* sums, MemberState* st, ConvParams p, hipStream_t s);
+void launch_finalize(const Grid& g, MemberState* st, int max_iter, hipStream_t s);
+void launch_state_init(const Grid& g, MemberState* st, hipStream_t s);
+void launch_copy2(const Grid& g, const float* src, float* dst0, float* dst1, hipStream_t s);
+void launch_negate(const Grid& g, const float* src, float* dst, hipStream_t s);
+void launch_cal_eta(const Grid& g, const float* psi, float* eta, const float* ra, const float* rcuva,
+                    const float* rho, const float* exner, hipStream_t s);
+void launch_cal_uw(const Grid& g, const float* psi, float* u, float* w, const float* ra,
+                   const float* za, const float* rcuva, const float* rho, hipStream_t s);
+// term planes of the EE integrals (then summed by launch_seqsum over [0,nx-1) x [0,ny-1))
+void launch_terms_weight(const Grid& g, const float* weight, float* terms, const float* ra,
+                         const float* za, const float* rcuva, const float* rho, hipStream_t s);
+void launch_terms_Qeta(const Grid& g, const float* Q, const float* eta, float* terms, const float* ra,
+                       const float* za, const float* rcuva, const float* rho, hipStream_t s);
+void launch_wtheta(const Grid& g, const float* w, const float* theta, float* out, hipStream_t s);
+void launch_rhs_thermal(const Grid& g, const float* Q, const float* ra, const float* exner,
+                        float* tmpC, float* rhs, hipStream_t s);
+void launch_rhs_from_B(const Grid& g, const float* b, float* f, hipStream_t s);
+void launch_coe_aos_to_soa(const Grid& g, const float* aos /* (9,nx,ny) packed */, float* coe, hipStream_t s);
+void launch_coe_soa_to_aos(const Grid& g, const float* coe, float* aos, hipStream_t s);
+size_t seqsum_lds_bytes(const Grid& g, int nrows);
+int    sweep_kernel_setup();   // one-time function attributes; returns hipError_t as int
+
+}  // namespace xee

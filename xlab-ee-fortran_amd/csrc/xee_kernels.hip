@@ -1,0 +1,666 @@
+// xee_kernels.hip -- hand-written HIP kernels for gfx950 (CDNA4, wave64) of the elliptic-solve hot
+// path.  Bit-exactness discipline (hard part 1):
+//   * compiled with -ffp-contract=off (and the pragma below): no v_fma/v_mac may be formed from the
+//     reference's separate multiplies and adds;
+//   * every expression keeps the reference's left-to-right association;
+//   * divisions are true IEEE divisions (hipcc's correctly-rounded v_div_scale/fmas/fixup
+//     sequence), never reciprocal-multiply; sqrt is correctly rounded; denormals are kept.
+// Lanes run along r (i, the contiguous index): every global access below is a coalesced
+// 256-byte-per-wave (dword) or 1-KiB-per-wave (dwordx4) row segment.
+#include "xee_device.h"
+
+#pragma clang fp contract(off)
+
+namespace xee {
+
+// physical constants, xtt-lib-fortran/constants.f90:4-5 (fp32, folded left to right)
+__device__ __forceinline__ float c_g0() { return 9.8f; }
+__device__ __forceinline__ float c_theta0() { return 298.0f; }
+__device__ __forceinline__ float c_Cp() { return 5.0f / 2.0f * 287.0f + 287.0f; }   // Cv + Rd = 1004.5
+
+// ---- cross-lane helpers: whole-wave shift by one lane (gfx9 DPP wave_shr / wave_shl) ----------
+// lane l receives src from lane l-1 (shr) / l+1 (shl); the lane with no source keeps `old`.
+__device__ __forceinline__ float wave_shr1(float old, float src)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old),
+                                     __builtin_bit_cast(int, src), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_shl1(float old, float src)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old),
+                                     __builtin_bit_cast(int, src), 0x130, 0xf, 0xf, false));
+}
+
+// =============================================================================================
+// K1  solver coefficients, src/diagnose/initialize-variables.f90:72-95
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_solver_coef(Grid g, const float* __restrict__ A,
+        const float* __restrict__ B, const float* __restrict__ C, const float* __restrict__ rcuva,
+        const float* __restrict__ rho, float* __restrict__ sA, float* __restrict__ sB,
+        float* __restrict__ sC)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int j = blockIdx.y * 4 + threadIdx.y;
+    const size_t mo = (size_t)blockIdx.z * g.plane;
+    if (i >= g.nx - 1 || j >= g.ny - 1) return;
+    const size_t o = mo + (size_t)j * g.pitch + i;
+    const float rs = rcuva[i] + rcuva[i + 1];
+    const float rj = rho[j] + rho[j + 1];
+    // solverB_B(I,J) = (B(I,J)+B(I+1,J)+B(I,J+1)+B(I+1,J+1)) / (rcuva(I)+rcuva(I+1)) / (rho(J)+rho(J+1))
+    sB[o] = (B[o] + B[o + 1] + B[o + g.pitch] + B[o + g.pitch + 1]) / rs / rj;
+    // solverA_A(I,J) = (A(I,J+1)+A(I+1,J+1)) / (rcuva(I)+rcuva(I+1)) / rho(J+1),  J <= nz-2
+    if (j < g.ny - 2) sA[o] = (A[o + g.pitch] + A[o + g.pitch + 1]) / rs / rho[j + 1];
+    // solverC_C(I,J) = (C(I+1,J)+C(I+1,J+1)) / rcuva(I+1) / (rho(J)+rho(J+1)),  I <= nr-2
+    if (i < g.nx - 2) sC[o] = (C[o + 1] + C[o + g.pitch + 1]) / rcuva[i + 1] / rj;
+}
+
+// =============================================================================================
+// K2  cal_coe, xtt-lib-fortran/elliptic_tools.f90:8-60  ->  nine SoA planes
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_cal_coe(Grid g, const float* __restrict__ a,
+        const float* __restrict__ b, const float* __restrict__ c, float* __restrict__ coe,
+        float dx, float dy)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int j = blockIdx.y * 4 + threadIdx.y;
+    if (i < 1 || i > g.nx - 2 || j < 1 || j > g.ny - 2) return;
+    const size_t mo = (size_t)blockIdx.z * g.plane;
+    const size_t o = mo + (size_t)j * g.pitch + i;       // (I,J) 1-based = (i+1, j+1)
+    const size_t om = o - g.pitch;                        // row J-1
+    const float PP = dx * dx, QQ = dy * dy, PQ4 = 4.0f * dx * dy;
+    const float two_PQ4 = 2.0f * PQ4;
+    const float Ap = a[om] / PP;                          // a(I  ,J-1)
+    const float Am = a[om - 1] / PP;                      // a(I-1,J-1)
+    const float Cp = c[o - 1] / QQ;                       // c(I-1,J  )
+    const float Cm = c[om - 1] / QQ;                      // c(I-1,J-1)
+    float b11 = 0.f, b10 = 0.f, b01 = 0.f, b00 = 0.f;     // b(I,J) b(I,J-1) b(I-1,J) b(I-1,J-1)
+    if (b) { b11 = b[o]; b10 = b[om]; b01 = b[o - 1]; b00 = b[om - 1]; }
+    const float BXp = (b11 + b10) / two_PQ4;
+    const float BXm = (b01 + b00) / two_PQ4;
+    const float BYp = (b01 + b11) / two_PQ4;
+    const float BYm = (b00 + b10) / two_PQ4;
+    const size_t ks = (size_t)g.members * g.plane;
+    coe[o + 0 * ks] = -(BXm + BYp);
+    coe[o + 1 * ks] = Cp + (BXp - BXm);
+    coe[o + 2 * ks] = BXp + BYp;
+    coe[o + 3 * ks] = Am - (BYp - BYm);
+    coe[o + 4 * ks] = -(Am + Ap + Cm + Cp);
+    coe[o + 5 * ks] = Ap + (BYp - BYm);
+    coe[o + 6 * ks] = BXm + BYm;
+    coe[o + 7 * ks] = Cm - (BXp - BXm);
+    coe[o + 8 * ks] = -(BXp + BYm);
+}
+
+// =============================================================================================
+// A2  do_elliptic, xtt-lib-fortran/elliptic_tools.f90:64-90 (stand-alone stencil apply)
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_apply(Grid g, const float* __restrict__ psi,
+        const float* __restrict__ coe, float* __restrict__ out)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int j = blockIdx.y * 4 + threadIdx.y;
+    if (i < 1 || i > g.nx - 2 || j < 1 || j > g.ny - 2) return;
+    const size_t o = (size_t)blockIdx.z * g.plane + (size_t)j * g.pitch + i;
+    const size_t ks = (size_t)g.members * g.plane;
+    const int p = g.pitch;
+    float r = coe[o] * psi[o + p - 1];
+    r = r + coe[o + 1 * ks] * psi[o + p];
+    r = r + coe[o + 2 * ks] * psi[o + p + 1];
+    r = r + coe[o + 3 * ks] * psi[o - 1];
+    r = r + coe[o + 4 * ks] * psi[o];
+    r = r + coe[o + 5 * ks] * psi[o + 1];
+    r = r + coe[o + 6 * ks] * psi[o - p - 1];
+    r = r + coe[o + 7 * ks] * psi[o - p];
+    r = r + coe[o + 8 * ks] * psi[o - p + 1];
+    out[o] = r;
+}
+
+// =============================================================================================
+// K3  one damped-Jacobi iteration, streaming form
+//     do_elliptic (:75-88), "- f" (:190), update (:236-240), fused; 48 B/point algorithmic.
+//     Thread = 4 consecutive r points (dwordx4 everywhere), marching RJ rows in z with the three
+//     psi rows held in registers; the i-1 / i+4 neighbours come from the adjacent lanes by DPP
+//     whole-wave shifts, the two wave-edge lanes load theirs.
+// =============================================================================================
+struct Row6 { float v[6]; };   // psi(i0-1 .. i0+4) of one row
+
+__device__ __forceinline__ Row6 load_row(const float* __restrict__ p, size_t rowoff, int i0,
+                                         bool valid, int lane, int pitch)
+{
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    float el = 0.f, er = 0.f;
+    if (valid) q = *reinterpret_cast<const float4*>(p + rowoff + i0);
+    if (lane == 0 && i0 > 0 && valid) el = p[rowoff + i0 - 1];
+    if (lane == 63 && i0 + 4 < pitch) er = p[rowoff + i0 + 4];
+    Row6 r;
+    r.v[0] = wave_shr1(el, q.w);
+    r.v[1] = q.x; r.v[2] = q.y; r.v[3] = q.z; r.v[4] = q.w;
+    r.v[5] = wave_shl1(er, q.x);
+    return r;
+}
+
+template <int RJ, bool WRITE_R>
+__global__ __launch_bounds__(256) void k_sweep_stream(Grid g, const float* __restrict__ psi_in,
+        float* __restrict__ psi_out, const float* __restrict__ coe, const float* __restrict__ f,
+        float* __restrict__ res, const MemberState* __restrict__ st, float alpha)
+{
+    const int m = blockIdx.z;
+    if (st && !st[m].active) return;                     // wave-uniform
+    const int lane = threadIdx.x;
+    const int i0 = (blockIdx.x * 64 + lane) * 4;
+    const bool valid = i0 < g.pitch;
+    const int jb = 1 + (blockIdx.y * 4 + threadIdx.y) * RJ;   // wave-uniform
+    if (jb > g.ny - 2) return;
+    const size_t mo = (size_t)m * g.plane;
+    const size_t ks = (size_t)g.members * g.plane;
+    const float* pin = psi_in + mo;
+
+    Row6 rm = load_row(pin, (size_t)(jb - 1) * g.pitch, i0, valid, lane, g.pitch);
+    Row6 rc = load_row(pin, (size_t)jb * g.pitch, i0, valid, lane, g.pitch);
+#pragma unroll
+    for (int r = 0; r < RJ; ++r) {
+        const int j = jb + r;
+        if (j > g.ny - 2) break;                         // wave-uniform
+        const size_t ro = (size_t)j * g.pitch;
+        Row6 rn = load_row(pin, ro + g.pitch, i0, valid, lane, g.pitch);
+        float4 c[9], ff = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) c[k] = *reinterpret_cast<const float4*>(coe + k * ks + mo + ro + i0);
+            ff = *reinterpret_cast<const float4*>(f + mo + ro + i0);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) c[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float outv[4], resv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float c1 = (&c[0].x)[q], c2 = (&c[1].x)[q], c3 = (&c[2].x)[q];
+            const float c4 = (&c[3].x)[q], c5 = (&c[4].x)[q], c6 = (&c[5].x)[q];
+            const float c7 = (&c[6].x)[q], c8 = (&c[7].x)[q], c9 = (&c[8].x)[q];
+            float R = c1 * rn.v[q];                      // psi(i-1,j+1)   elliptic_tools.f90:77
+            R = R + c2 * rn.v[q + 1];
+            R = R + c3 * rn.v[q + 2];
+            R = R + c4 * rc.v[q];
+            R = R + c5 * rc.v[q + 1];
+            R = R + c6 * rc.v[q + 2];
+            R = R + c7 * rm.v[q];
+            R = R + c8 * rm.v[q + 1];
+            R = R + c9 * rm.v[q + 2];                    // :85
+            R = R - (&ff.x)[q];                          // :190
+            const float upd = rc.v[q + 1] + alpha * R / (-c5);   // :238
+            const int ii = i0 + q;
+            const bool interior = (ii >= 1) && (ii <= g.nx - 2);
+            outv[q] = interior ? upd : rc.v[q + 1];      // rim (and padding) keeps its value
+            resv[q] = interior ? R : 0.f;
+        }
+        if (valid) {
+            *reinterpret_cast<float4*>(psi_out + mo + ro + i0) = make_float4(outv[0], outv[1], outv[2], outv[3]);
+            if (WRITE_R)
+                *reinterpret_cast<float4*>(res + mo + ro + i0) = make_float4(resv[0], resv[1], resv[2], resv[3]);
+        }
+        rm = rc;
+        rc = rn;
+    }
+}
+
+// =============================================================================================
+// K4  order-exact residual norm / domain integrals: sequential fp32 sum, i outer / j inner
+//     (elliptic_tools.f90:193-199; old-diagnose/diagnose.f90:1035-1046).  One workgroup per member:
+//     waves 1-3 stage the next TC columns transposed (and squared) into LDS while lane 0 of wave 0
+//     walks the current ones in reference order.
+// =============================================================================================
+template <bool SQUARE>
+__global__ __launch_bounds__(256) void k_seqsum(Grid g, const float* __restrict__ T, int i0, int i1,
+        int j0, int j1, int TC, int colstride, float* __restrict__ out,
+        const MemberState* __restrict__ st)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int m = blockIdx.x;
+    if (st && !st[m].active) return;
+    const float* Tm = T + (size_t)m * g.plane;
+    const int nrows = j1 - j0, ncols = i1 - i0;
+    const int ntiles = (ncols + TC - 1) / TC;
+    const int tid = threadIdx.x;
+    float s = 0.0f;
+
+    auto load_tile = [&](int t, int first, int nthr) {
+        float* buf = lds + (size_t)(t & 1) * TC * colstride;
+        const int cbase = i0 + t * TC;
+        const int total = TC * nrows;
+        for (int e = tid - first; e < total; e += nthr) {
+            const int cidx = e % TC, r = e / TC;
+            if (cbase + cidx < i1) {
+                const float x = Tm[(size_t)(j0 + r) * g.pitch + cbase + cidx];
+                buf[cidx * colstride + r] = SQUARE ? x * x : x;   // to_dat(i,j)**2.0
+            }
+        }
+    };
+
+    load_tile(0, 0, 256);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        if (tid >= 64) {
+            if (t + 1 < ntiles) load_tile(t + 1, 64, 192);
+        } else if (tid == 0) {
+            const float* buf = lds + (size_t)(t & 1) * TC * colstride;
+            const int nc = min(TC, ncols - t * TC);
+            for (int cidx = 0; cidx < nc; ++cidx) {
+                const float* col = buf + cidx * colstride;
+                int r = 0;
+                for (; r + 4 <= nrows; r += 4) {
+                    const float4 q = *reinterpret_cast<const float4*>(col + r);
+                    s = s + q.x; s = s + q.y; s = s + q.z; s = s + q.w;
+                }
+                for (; r < nrows; ++r) s = s + col[r];
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) out[m] = s;
+}
+
+// convergence state machine, elliptic_tools.f90:199-234 and :242-256; one lane per member
+__global__ void k_conv_update(Grid g, const float* __restrict__ sums, MemberState* __restrict__ st,
+                              ConvParams p)
+{
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= g.members) return;
+    MemberState s = st[m];
+    if (!s.active) return;
+    const float err_now = sqrtf(sums[m] / (float)p.n_interior);          // :199
+    float ratio = (s.err_before - err_now) / s.err_before;                // :201
+    if (p.debug == 2) printf("Iter: %8d, err_now: %12.3E, ratio: %12.3E\n", p.cnt, err_now, ratio);
+    ratio = fabsf(ratio);
+    bool stop = false;
+    if (s.err_before == 0.0f) {
+        stop = true;
+    } else if (err_now < p.r1 && ratio < p.r2) {
+        s.converge_cnt += 1;
+        s.lose_cnt = 0;
+        if (s.converge_cnt >= p.converge_time) stop = true;
+    } else if (s.converge_cnt > 0) {
+        s.lose_cnt += 1;
+        if (s.lose_cnt >= p.lost_rate) { s.converge_cnt -= 1; s.lose_cnt = 0; }
+    }
+    s.err_before = err_now;
+    s.err_now = err_now;
+    s.ratio = ratio;
+    if (p.is_last) { stop = true; s.err_bits |= 1; }                      // :242-248
+    if (stop) { s.active = 0; s.iters = p.cnt; }
+    st[m] = s;
+}
+
+// max_iter reached on an iteration that is not a check iteration (:242-248)
+__global__ void k_finalize(Grid g, MemberState* __restrict__ st, int max_iter)
+{
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= g.members) return;
+    if (st[m].active) { st[m].active = 0; st[m].iters = max_iter; st[m].err_bits |= 1; }
+}
+
+__global__ void k_state_init(Grid g, MemberState* __restrict__ st)
+{
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= g.members) return;
+    MemberState s;
+    s.active = 1; s.iters = 0; s.err_bits = 0; s.converge_cnt = 0; s.lose_cnt = 0;
+    s.err_before = 3.40282347e+38f;   // HUGE(err_before), :163
+    s.err_now = 0.0f; s.ratio = 0.0f;
+    st[m] = s;
+}
+
+// =============================================================================================
+// plane utilities (dwordx4, whole padded planes)
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_copy2(size_t n4, const float4* __restrict__ src,
+                                               float4* __restrict__ d0, float4* __restrict__ d1)
+{
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n4; k += (size_t)gridDim.x * 256) {
+        const float4 v = src[k];
+        d0[k] = v;
+        if (d1) d1[k] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_negate(size_t n4, const float4* __restrict__ src,
+                                                float4* __restrict__ dst)
+{
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n4; k += (size_t)gridDim.x * 256) {
+        const float4 v = src[k];
+        dst[k] = make_float4(-v.x, -v.y, -v.z, -v.w);    // forcing_in = -rhoB_in
+    }
+}
+
+// =============================================================================================
+// K5  cal_eta = d_rcuvdr_O2A then scaling, quick-tools1.f90:1-13, quick-tools2.f90:59-85
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_cal_eta(Grid g, const float* __restrict__ psi,
+        float* __restrict__ eta, const float* __restrict__ ra, const float* __restrict__ rcuva,
+        const float* __restrict__ rho, const float* __restrict__ exner)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int j = blockIdx.y * 4 + threadIdx.y;
+    if (i >= g.nx - 1 || j >= g.ny) return;
+    const size_t o = (size_t)blockIdx.z * g.plane + (size_t)j * g.pitch + i;
+    float t = (psi[o + 1] - psi[o]) / (ra[i + 1] - ra[i]);               // d_dr_O2A
+    t = t / ((rcuva[i] + rcuva[i + 1]) / 2.0f);                          // d_rcuvdr_O2A
+    eta[o] = t * c_g0() / (rho[j] * c_Cp() * exner[j] * c_theta0());     // cal_eta :10
+}
+
+// =============================================================================================
+// K6  cal_uw, quick-tools1.f90:15-41 (+ d_dz_O2C quick-tools2.f90:16-25)
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_cal_uw(Grid g, const float* __restrict__ psi,
+        float* __restrict__ u, float* __restrict__ w, const float* __restrict__ ra,
+        const float* __restrict__ za, const float* __restrict__ rcuva, const float* __restrict__ rho)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int j = blockIdx.y * 4 + threadIdx.y;
+    if (i >= g.nx || j >= g.ny) return;
+    const size_t o = (size_t)blockIdx.z * g.plane + (size_t)j * g.pitch + i;
+    if (i < g.nx - 1) {
+        float t = (psi[o + 1] - psi[o]) / (ra[i + 1] - ra[i]);
+        t = t / ((rcuva[i] + rcuva[i + 1]) / 2.0f);
+        w[o] = t / rho[j];
+    }
+    if (j < g.ny - 1) {
+        float t = (psi[o + g.pitch] - psi[o]) / (za[j + 1] - za[j]);
+        t = -t;
+        if (ra[i] != 0.0f) t = t / (rcuva[i] * (rho[j] + rho[j + 1]) / 2.0f);
+        else t = 0.0f;
+        u[o] = t;
+    }
+}
+
+// =============================================================================================
+// K8  EE domain integrals: per-cell terms (then k_seqsum), old-diagnose/diagnose.f90:1029-1092
+// =============================================================================================
+__device__ __forceinline__ float cell_measure(float wgt, int i, int j, const float* ra, const float* za,
+                                              const float* rcuva, const float* rho)
+{
+    const float rcuv = (rcuva[i] + rcuva[i + 1]) / 2.0f;
+    const float dr = ra[i + 1] - ra[i];
+    const float dz = za[j + 1] - za[j];
+    const float rho_ = (rho[j + 1] + rho[j]) / 2.0f;
+    return wgt * rho_ * rcuv * dr * dz;                                  // left to right, :1044
+}
+
+__global__ __launch_bounds__(256) void k_terms_weight(Grid g, const float* __restrict__ wgt,
+        float* __restrict__ terms, const float* __restrict__ ra, const float* __restrict__ za,
+        const float* __restrict__ rcuva, const float* __restrict__ rho)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int j = blockIdx.y * 4 + threadIdx.y;
+    if (i >= g.nx - 1 || j >= g.ny - 1) return;
+    const size_t o = (size_t)blockIdx.z * g.plane + (size_t)j * g.pitch + i;
+    terms[o] = cell_measure(wgt[o], i, j, ra, za, rcuva, rho);
+}
+
+__global__ __launch_bounds__(256) void k_terms_Qeta(Grid g, const float* __restrict__ Q,
+        const float* __restrict__ eta, float* __restrict__ terms, const float* __restrict__ ra,
+        const float* __restrict__ za, const float* __restrict__ rcuva, const float* __restrict__ rho)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int j = blockIdx.y * 4 + threadIdx.y;
+    if (i >= g.nx - 1 || j >= g.ny - 1) return;
+    const size_t o = (size_t)blockIdx.z * g.plane + (size_t)j * g.pitch + i;
+    const float e = (eta[o] + eta[o + g.pitch]) / 2.0f;                  // :1088
+    terms[o] = cell_measure(e * Q[o], i, j, ra, za, rcuva, rho);
+}
+
+// cal_wtheta, old-diagnose/diagnose.f90:1117-1127
+__global__ __launch_bounds__(256) void k_wtheta(Grid g, const float* __restrict__ w,
+        const float* __restrict__ theta, float* __restrict__ out)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int j = blockIdx.y * 4 + threadIdx.y;
+    if (i >= g.nx - 1 || j >= g.ny - 1) return;
+    const size_t o = (size_t)blockIdx.z * g.plane + (size_t)j * g.pitch + i;
+    out[o] = ((w[o] + w[o + g.pitch]) / 2.0f) * theta[o];
+}
+
+// =============================================================================================
+// K7  RHS source-term assembly, old-diagnose/diagnose.f90:383-387, 395-406, 523-538
+// =============================================================================================
+// pass 1: wksp_C(I,J) = (JJ(I,J)-JJ(I-1,J)) / ((ra(I+1)-ra(I-1))/2), JJ = Q/(Cp*exner(J)); I=2..nr-1
+__global__ __launch_bounds__(256) void k_rhs_thermal_1(Grid g, const float* __restrict__ Q,
+        const float* __restrict__ ra, const float* __restrict__ exner, float* __restrict__ tmpC)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int j = blockIdx.y * 4 + threadIdx.y;
+    if (i >= g.nx || j >= g.ny - 1) return;
+    const size_t o = (size_t)blockIdx.z * g.plane + (size_t)j * g.pitch + i;
+    float v = 0.0f;
+    if (i >= 1 && i <= g.nx - 2) {
+        const float d = c_Cp() * exner[j];
+        v = (Q[o] / d - Q[o - 1] / d) / ((ra[i + 1] - ra[i - 1]) / 2.0f);
+    }
+    tmpC[o] = v;
+}
+// pass 2: RHS(I,J) = (wksp_C(I,J)+wksp_C(I,J-1))/2 * g0 / theta0 on the interior, 0 elsewhere
+__global__ __launch_bounds__(256) void k_rhs_thermal_2(Grid g, const float* __restrict__ tmpC,
+        float* __restrict__ rhs)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int j = blockIdx.y * 4 + threadIdx.y;
+    if (i >= g.nx || j >= g.ny) return;
+    const size_t o = (size_t)blockIdx.z * g.plane + (size_t)j * g.pitch + i;
+    float v = 0.0f;
+    if (i >= 1 && i <= g.nx - 2 && j >= 1 && j <= g.ny - 2) v = (tmpC[o] + tmpC[o - g.pitch]) / 2.0f;
+    rhs[o] = v * c_g0() / c_theta0();
+}
+// f(I,J) = -(b(I-1,J-1)+b(I-1,J)+b(I,J)+b(I,J-1))/4 on the interior, 0 elsewhere
+__global__ __launch_bounds__(256) void k_rhs_from_B(Grid g, const float* __restrict__ b,
+        float* __restrict__ f)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int j = blockIdx.y * 4 + threadIdx.y;
+    if (i >= g.nx || j >= g.ny) return;
+    const size_t o = (size_t)blockIdx.z * g.plane + (size_t)j * g.pitch + i;
+    float v = 0.0f;
+    if (i >= 1 && i <= g.nx - 2 && j >= 1 && j <= g.ny - 2)
+        v = -(b[o - g.pitch - 1] + b[o - 1] + b[o] + b[o - g.pitch]) / 4.0f;
+    f[o] = v;
+}
+
+// =============================================================================================
+// Tier-1 boundary: reference AoS coe(9,nx,ny) <-> nine SoA planes
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_coe_aos_to_soa(Grid g, const float* __restrict__ aos,
+                                                        float* __restrict__ coe)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int j = blockIdx.y * 4 + threadIdx.y;
+    if (i >= g.nx || j >= g.ny) return;
+    const bool interior = i >= 1 && i <= g.nx - 2 && j >= 1 && j <= g.ny - 2;
+    const size_t o = (size_t)j * g.pitch + i;
+    const size_t ks = (size_t)g.members * g.plane;
+    const float* src = aos + ((size_t)j * g.nx + i) * 9;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) coe[o + k * ks] = interior ? src[k] : 0.0f;   // rim entries undefined in the reference
+}
+
+__global__ __launch_bounds__(256) void k_coe_soa_to_aos(Grid g, const float* __restrict__ coe,
+                                                        float* __restrict__ aos)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int j = blockIdx.y * 4 + threadIdx.y;
+    if (i < 1 || i > g.nx - 2 || j < 1 || j > g.ny - 2) return;
+    const size_t o = (size_t)j * g.pitch + i;
+    const size_t ks = (size_t)g.members * g.plane;
+    float* dst = aos + ((size_t)j * g.nx + i) * 9;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) dst[k] = coe[o + k * ks];
+}
+
+// =============================================================================================
+// launch wrappers
+// =============================================================================================
+static inline dim3 grid2d(const Grid& g) { return dim3((g.nx + 63) / 64, (g.ny + 3) / 4, g.members); }
+static const dim3 kBlk(64, 4, 1);
+
+void launch_solver_coef(const Grid& g, const float* A, const float* B, const float* C,
+                        const float* rcuva, const float* rho, float* sA, float* sB, float* sC,
+                        hipStream_t s)
+{
+    hipLaunchKernelGGL(k_solver_coef, grid2d(g), kBlk, 0, s, g, A, B, C, rcuva, rho, sA, sB, sC);
+}
+
+void launch_cal_coe(const Grid& g, const float* sA, const float* sB, const float* sC, float* coe,
+                    float dx, float dy, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_cal_coe, grid2d(g), kBlk, 0, s, g, sA, sB, sC, coe, dx, dy);
+}
+
+void launch_apply(const Grid& g, const float* psi, const float* coe, float* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_apply, grid2d(g), kBlk, 0, s, g, psi, coe, out);
+}
+
+template <int RJ>
+static void launch_sweep_rj(const Grid& g, const float* psi_in, float* psi_out, const float* coe,
+                            const float* f, float* res, const MemberState* st, float alpha, hipStream_t s)
+{
+    dim3 grid((g.pitch / 4 + 63) / 64, (g.ny - 2 + 4 * RJ - 1) / (4 * RJ), g.members);
+    if (res)
+        hipLaunchKernelGGL((k_sweep_stream<RJ, true>), grid, kBlk, 0, s, g, psi_in, psi_out, coe, f, res, st, alpha);
+    else
+        hipLaunchKernelGGL((k_sweep_stream<RJ, false>), grid, kBlk, 0, s, g, psi_in, psi_out, coe, f, res, st, alpha);
+}
+
+void launch_sweep(const Grid& g, const float* psi_in, float* psi_out, const float* coe,
+                  const float* f, float* res, const MemberState* st, float alpha, hipStream_t s)
+{
+    // rows marched per thread: as many as still leave >= ~8 workgroups per CU (256 CUs)
+    const long bx = (g.pitch / 4 + 63) / 64;
+    auto blocks = [&](int rj) { return bx * ((g.ny - 2 + 4 * rj - 1) / (4 * rj)) * (long)g.members; };
+    if (blocks(8) >= 2048) launch_sweep_rj<8>(g, psi_in, psi_out, coe, f, res, st, alpha, s);
+    else if (blocks(4) >= 2048) launch_sweep_rj<4>(g, psi_in, psi_out, coe, f, res, st, alpha, s);
+    else if (blocks(2) >= 1024) launch_sweep_rj<2>(g, psi_in, psi_out, coe, f, res, st, alpha, s);
+    else launch_sweep_rj<1>(g, psi_in, psi_out, coe, f, res, st, alpha, s);
+}
+
+static void seqsum_shape(const Grid& g, int nrows, int* TC, int* colstride)
+{
+    (void)g;
+    int cs = ((nrows + 3) / 4) * 4 + 4;          // 16-byte aligned columns, off the power-of-two stride
+    int tc = 64;
+    while (tc > 1 && (size_t)2 * tc * cs * sizeof(float) > 128 * 1024) tc >>= 1;
+    *TC = tc;
+    *colstride = cs;
+}
+
+size_t seqsum_lds_bytes(const Grid& g, int nrows)
+{
+    int tc, cs;
+    seqsum_shape(g, nrows, &tc, &cs);
+    return (size_t)2 * tc * cs * sizeof(float);
+}
+
+int sweep_kernel_setup()
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seqsum<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seqsum<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return (int)e;
+}
+
+void launch_seqsum(const Grid& g, const float* T, int i0, int i1, int j0, int j1, bool square,
+                   float* out_sums, const MemberState* st, hipStream_t s)
+{
+    int tc, cs;
+    seqsum_shape(g, j1 - j0, &tc, &cs);
+    const size_t lds = (size_t)2 * tc * cs * sizeof(float);
+    if (square)
+        hipLaunchKernelGGL((k_seqsum<true>), dim3(g.members), dim3(256), lds, s, g, T, i0, i1, j0, j1, tc, cs, out_sums, st);
+    else
+        hipLaunchKernelGGL((k_seqsum<false>), dim3(g.members), dim3(256), lds, s, g, T, i0, i1, j0, j1, tc, cs, out_sums, st);
+}
+
+void launch_conv_update(const Grid& g, const float* sums, MemberState* st, ConvParams p, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_conv_update, dim3((g.members + 63) / 64), dim3(64), 0, s, g, sums, st, p);
+}
+
+void launch_finalize(const Grid& g, MemberState* st, int max_iter, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_finalize, dim3((g.members + 63) / 64), dim3(64), 0, s, g, st, max_iter);
+}
+
+void launch_state_init(const Grid& g, MemberState* st, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_state_init, dim3((g.members + 63) / 64), dim3(64), 0, s, g, st);
+}
+
+static inline int stream_blocks(size_t n4) { return (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048); }
+
+void launch_copy2(const Grid& g, const float* src, float* dst0, float* dst1, hipStream_t s)
+{
+    const size_t n4 = g.plane * g.members / 4;
+    hipLaunchKernelGGL(k_copy2, dim3(stream_blocks(n4)), dim3(256), 0, s, n4,
+                       reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst0),
+                       reinterpret_cast<float4*>(dst1));
+}
+
+void launch_negate(const Grid& g, const float* src, float* dst, hipStream_t s)
+{
+    const size_t n4 = g.plane * g.members / 4;
+    hipLaunchKernelGGL(k_negate, dim3(stream_blocks(n4)), dim3(256), 0, s, n4,
+                       reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst));
+}
+
+void launch_cal_eta(const Grid& g, const float* psi, float* eta, const float* ra, const float* rcuva,
+                    const float* rho, const float* exner, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_cal_eta, grid2d(g), kBlk, 0, s, g, psi, eta, ra, rcuva, rho, exner);
+}
+
+void launch_cal_uw(const Grid& g, const float* psi, float* u, float* w, const float* ra,
+                   const float* za, const float* rcuva, const float* rho, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_cal_uw, grid2d(g), kBlk, 0, s, g, psi, u, w, ra, za, rcuva, rho);
+}
+
+void launch_terms_weight(const Grid& g, const float* weight, float* terms, const float* ra,
+                         const float* za, const float* rcuva, const float* rho, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_terms_weight, grid2d(g), kBlk, 0, s, g, weight, terms, ra, za, rcuva, rho);
+}
+
+void launch_terms_Qeta(const Grid& g, const float* Q, const float* eta, float* terms, const float* ra,
+                       const float* za, const float* rcuva, const float* rho, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_terms_Qeta, grid2d(g), kBlk, 0, s, g, Q, eta, terms, ra, za, rcuva, rho);
+}
+
+void launch_wtheta(const Grid& g, const float* w, const float* theta, float* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_wtheta, grid2d(g), kBlk, 0, s, g, w, theta, out);
+}
+
+void launch_rhs_thermal(const Grid& g, const float* Q, const float* ra, const float* exner,
+                        float* tmpC, float* rhs, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_rhs_thermal_1, grid2d(g), kBlk, 0, s, g, Q, ra, exner, tmpC);
+    hipLaunchKernelGGL(k_rhs_thermal_2, grid2d(g), kBlk, 0, s, g, tmpC, rhs);
+}
+
+void launch_rhs_from_B(const Grid& g, const float* b, float* f, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_rhs_from_B, grid2d(g), kBlk, 0, s, g, b, f);
+}
+
+void launch_coe_aos_to_soa(const Grid& g, const float* aos, float* coe, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_coe_aos_to_soa, grid2d(g), kBlk, 0, s, g, aos, coe);
+}
+
+void launch_coe_soa_to_aos(const Grid& g, const float* coe, float* aos, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_coe_soa_to_aos, grid2d(g), kBlk, 0, s, g, coe, aos);
+}
+
+}  // namespace xee

@@ -1,0 +1,368 @@
+"""ctypes view of libxee's C-ABI (include/xee.h).  Plumbing only: numpy arrays <-> C pointers.
+
+There is deliberately no fallback: if lib/libxee.so is missing or a call fails, XeeError is raised
+(the product path must fail loudly when the HIP extension is absent).
+
+Array convention (same as the C-ABI): a Fortran array f(n1,n2) is a numpy (n2,n1) C-order float32
+array -- the byte layout of the reference's .bin files (xtt-lib-fortran/field_tools.f90:30-76).
+"""
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+
+BAROTROPIC, BAROCLINIC = 0, 1
+SOLVE_DEFAULT, SOLVE_SINGLE_STEP, SOLVE_KEEP_PSI, SOLVE_TRACE = 0, 1, 2, 4
+
+FIELDS = {"A": 0, "B": 1, "C": 2, "BC_INIT": 3, "FORCING": 4, "PSI": 5, "SOLVER_A": 6, "SOLVER_B": 7,
+          "SOLVER_C": 8, "ETA": 9, "U": 10, "W": 11, "Q": 12, "RESIDUAL": 13}
+FIELDS.update({f"COE{k}": 16 + k for k in range(9)})
+
+_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_pi = C.POINTER(C.c_int)
+_pf = C.POINTER(C.c_float)
+
+
+class XeeError(RuntimeError):
+    def __init__(self, status, text):
+        super().__init__(f"libxee status {status}: {text}")
+        self.status = status
+
+
+class CaseRecord(C.Structure):
+    """xee_case_record_t (128 bytes) -- the unit of the multi-GPU gather."""
+    _fields_ = [("case_id", C.c_int32), ("iters", C.c_int32), ("err_bits", C.c_int32), ("reserved", C.c_int32),
+                ("err_now", C.c_float), ("ratio", C.c_float), ("sum_Q", C.c_float), ("sum_Qeta", C.c_float),
+                ("efficiency", C.c_float), ("scalars", C.c_float * 23)]
+
+
+RECORD_DTYPE = np.dtype([("case_id", "<i4"), ("iters", "<i4"), ("err_bits", "<i4"), ("reserved", "<i4"),
+                         ("err_now", "<f4"), ("ratio", "<f4"), ("sum_Q", "<f4"), ("sum_Qeta", "<f4"),
+                         ("efficiency", "<f4"), ("scalars", "<f4", (23,))])
+assert RECORD_DTYPE.itemsize == 128 and C.sizeof(CaseRecord) == 128
+
+
+class Timing(C.Structure):
+    _fields_ = [("solve_ms", C.c_double), ("sweep_ms", C.c_double), ("sweep_launches", C.c_int64),
+                ("iterations", C.c_int64), ("check_launches", C.c_int64)]
+
+
+_lib = None
+
+
+def lib_path():
+    return _HERE / "lib" / "libxee.so"
+
+
+def lib():
+    """Load lib/libxee.so (built by `make -C xlab-ee-fortran_amd lib` / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not p.exists():
+        raise XeeError(-1, f"{p} is missing: build it with `make -C {_HERE} lib` (no CPU fallback exists)")
+    L = C.CDLL(str(p))
+    L.xee_last_error.restype = C.c_char_p
+    L.xee_device_count.argtypes = [_pi]
+    L.xee_profiles.argtypes = [C.c_int, C.c_int, _f32p, C.c_int, C.c_int, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _pf, _pf]
+    L.xee_cal_coe.argtypes = [_f32p, _f32p, _f32p, _f32p, C.c_float, C.c_float, C.c_int, C.c_int, _pi]
+    L.xee_do_elliptic.argtypes = [_f32p, _f32p, _f32p, C.c_int, C.c_int, _pi]
+    L.xee_solve_elliptic.argtypes = [_pi, C.c_int, C.c_int, C.c_int, _pf, _pf, C.c_float, _f32p, _f32p, _f32p, _f32p,
+                                     C.c_int, C.c_int, _pi, C.c_int]
+    L.xee_judge_error.argtypes = [C.c_int]
+    L.xee_judge_error.restype = None
+    L.xee_solver_coefficients.argtypes = [_f32p] * 8 + [C.c_int, C.c_int]
+    L.xee_cal_eta.argtypes = [_f32p] * 6 + [C.c_int, C.c_int]
+    L.xee_cal_uw.argtypes = [_f32p] * 7 + [C.c_int, C.c_int]
+    L.xee_integrate_weight_B.argtypes = [_f32p] * 5 + [C.c_int, C.c_int, _pf]
+    L.xee_cal_sum_Qeta.argtypes = [_f32p] * 6 + [C.c_int, C.c_int, _pf]
+    L.xee_cal_wtheta.argtypes = [_f32p] * 3 + [C.c_int, C.c_int]
+    L.xee_rhs_thermal.argtypes = [_f32p] * 4 + [C.c_int, C.c_int]
+    L.xee_rhs_from_B.argtypes = [_f32p] * 2 + [C.c_int, C.c_int]
+    vp = C.c_void_p
+    L.xee_ensemble_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int]
+    L.xee_ensemble_destroy.argtypes = [vp]
+    L.xee_ensemble_set_stream.argtypes = [vp, vp]
+    L.xee_ensemble_set_case_ids.argtypes = [vp, C.c_int]
+    L.xee_ensemble_set_profiles.argtypes = [vp, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_float, C.c_float]
+    L.xee_ensemble_upload.argtypes = [vp, C.c_int, C.c_int, C.c_int, _f32p]
+    L.xee_ensemble_download.argtypes = [vp, C.c_int, C.c_int, C.c_int, _f32p]
+    L.xee_ensemble_device_plane.argtypes = [vp, C.c_int, C.POINTER(vp), _pi, C.POINTER(C.c_size_t), _pi, _pi]
+    L.xee_ensemble_forcing_from_B.argtypes = [vp]
+    L.xee_ensemble_assemble.argtypes = [vp, C.c_int]
+    L.xee_ensemble_solve.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int]
+    L.xee_ensemble_cal_eta.argtypes = [vp]
+    L.xee_ensemble_cal_uw.argtypes = [vp]
+    L.xee_ensemble_ee_scalars.argtypes = [vp]
+    L.xee_ensemble_records.argtypes = [vp, C.c_void_p]
+    L.xee_ensemble_timing.argtypes = [vp, C.POINTER(Timing)]
+    L.xee_ensemble_time_sweeps.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    _lib = L
+    return L
+
+
+def _chk(status):
+    if status != 0:
+        raise XeeError(status, lib().xee_last_error().decode(errors="replace"))
+
+
+def _a(x):
+    return np.ascontiguousarray(x, dtype=np.float32)
+
+
+def device_count():
+    n = C.c_int(0)
+    _chk(lib().xee_device_count(C.byref(n)))
+    return n.value
+
+
+# ---- Tier 1 wrappers (same names and argument meaning as the reference procedures) ----------
+
+def profiles(nr, nz, geometry=0, density_mode=0, domain=(0.0, 1.0, 0.0, 1.0)):
+    """initialize-variables.f90:44-67 -> dict(ra, za, rcuva, exner, rho, sin_table, dr, dz)."""
+    dom = np.zeros(4, np.float32)
+    dom[: len(domain)] = domain
+    out = {k: np.zeros(nr if k in ("ra", "rcuva", "sin_table") else nz, np.float32)
+           for k in ("ra", "za", "rcuva", "exner", "rho", "sin_table")}
+    dr, dz = C.c_float(), C.c_float()
+    _chk(lib().xee_profiles(geometry, density_mode, dom, nr, nz, out["ra"], out["za"], out["rcuva"],
+                            out["exner"], out["rho"], out["sin_table"], C.byref(dr), C.byref(dz)))
+    out["dr"], out["dz"] = np.float32(dr.value), np.float32(dz.value)
+    return out
+
+
+def cal_coe(a, b, c, dx, dy, nx, ny, coe=None):
+    """elliptic_tools.f90:8-60 -> coe (ny,nx,9); rim entries keep the bytes of `coe` (zeros by default)."""
+    coe = np.zeros((ny, nx, 9), np.float32) if coe is None else _a(coe)
+    err = C.c_int(-1)
+    _chk(lib().xee_cal_coe(_a(a), _a(b), _a(c), coe, float(dx), float(dy), nx, ny, C.byref(err)))
+    return coe, err.value
+
+
+def do_elliptic(psi, coe, outdat=None):
+    ny, nx = psi.shape
+    out = np.zeros((ny, nx), np.float32) if outdat is None else _a(outdat).copy()
+    err = C.c_int(0)
+    _chk(lib().xee_do_elliptic(_a(psi), _a(coe), out, nx, ny, C.byref(err)))
+    return out, err.value
+
+
+def solve_elliptic(dat, coe, f, max_iter, r1, r2, alpha, check_step=100, converge_time=10, lost_rate=5, debug=0):
+    """elliptic_tools.f90:93-265 -> (psi, iters, err_bits, r1_out, r2_out)."""
+    ny, nx = dat.shape
+    psi = _a(dat).copy()
+    wk = np.zeros_like(psi)
+    mi, e = C.c_int(int(max_iter)), C.c_int(0)
+    a, b = C.c_float(r1), C.c_float(r2)
+    _chk(lib().xee_solve_elliptic(C.byref(mi), check_step, converge_time, lost_rate, C.byref(a), C.byref(b),
+                                  float(alpha), psi, _a(coe), _a(f), wk, nx, ny, C.byref(e), debug))
+    return psi, mi.value, e.value, np.float32(a.value), np.float32(b.value)
+
+
+def solver_coefficients(A, B, Cc, rcuva, rho):
+    nz, nr = A.shape
+    sA = np.zeros((nz - 2, nr - 1), np.float32)
+    sB = np.zeros((nz - 1, nr - 1), np.float32)
+    sC = np.zeros((nz - 1, nr - 2), np.float32)
+    _chk(lib().xee_solver_coefficients(_a(A), _a(B), _a(Cc), _a(rcuva), _a(rho), sA, sB, sC, nr, nz))
+    return sA, sB, sC
+
+
+def cal_eta(rchi, prof):
+    nz, nr = rchi.shape
+    eta = np.zeros((nz, nr - 1), np.float32)
+    _chk(lib().xee_cal_eta(_a(rchi), eta, prof["ra"], prof["rcuva"], prof["rho"], prof["exner"], nr, nz))
+    return eta
+
+
+def cal_uw(rpsi, prof):
+    nz, nr = rpsi.shape
+    u = np.zeros((nz - 1, nr), np.float32)
+    w = np.zeros((nz, nr - 1), np.float32)
+    _chk(lib().xee_cal_uw(_a(rpsi), u, w, prof["ra"], prof["za"], prof["rcuva"], prof["rho"], nr, nz))
+    return u, w
+
+
+def integrate_weight_B(weight, prof):
+    nzm, nrm = weight.shape
+    s = C.c_float()
+    _chk(lib().xee_integrate_weight_B(_a(weight), prof["ra"], prof["za"], prof["rcuva"], prof["rho"],
+                                      nrm + 1, nzm + 1, C.byref(s)))
+    return np.float32(s.value)
+
+
+def cal_sum_Qeta(Q, eta, prof):
+    nzm, nrm = Q.shape
+    s = C.c_float()
+    _chk(lib().xee_cal_sum_Qeta(_a(Q), _a(eta), prof["ra"], prof["za"], prof["rcuva"], prof["rho"],
+                                nrm + 1, nzm + 1, C.byref(s)))
+    return np.float32(s.value)
+
+
+def cal_wtheta(w_A, theta_B):
+    nz, nrm = w_A.shape
+    out = np.zeros((nz - 1, nrm), np.float32)
+    _chk(lib().xee_cal_wtheta(_a(w_A), _a(theta_B), out, nrm + 1, nz))
+    return out
+
+
+def rhs_thermal(Q_B, ra, exner):
+    nzm, nrm = Q_B.shape
+    out = np.zeros((nzm + 1, nrm + 1), np.float32)
+    _chk(lib().xee_rhs_thermal(_a(Q_B), _a(ra), _a(exner), out, nrm + 1, nzm + 1))
+    return out
+
+
+def rhs_from_B(b_B):
+    nzm, nrm = b_B.shape
+    out = np.zeros((nzm + 1, nrm + 1), np.float32)
+    _chk(lib().xee_rhs_from_B(_a(b_B), out, nrm + 1, nzm + 1))
+    return out
+
+
+# ---- Tier 2: device-resident ensemble ---------------------------------------------------------
+
+class Ensemble:
+    """N independent cases of one grid on one GPU (xee_ensemble_* of include/xee.h)."""
+
+    def __init__(self, nr, nz, members=1, device=-1):
+        self.nr, self.nz, self.members = nr, nz, members
+        self._h = C.c_void_p()
+        _chk(lib().xee_ensemble_create(C.byref(self._h), nr, nz, members, device))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().xee_ensemble_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _shape(self, field):
+        nr, nz = self.nr, self.nz
+        return {"SOLVER_A": (nz - 2, nr - 1), "SOLVER_B": (nz - 1, nr - 1), "SOLVER_C": (nz - 1, nr - 2),
+                "ETA": (nz, nr - 1), "U": (nz - 1, nr), "W": (nz, nr - 1), "Q": (nz - 1, nr - 1)}.get(field, (nz, nr))
+
+    def set_stream(self, hip_stream):
+        _chk(lib().xee_ensemble_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def set_case_ids(self, first):
+        _chk(lib().xee_ensemble_set_case_ids(self._h, first))
+
+    def set_profiles(self, prof):
+        self.prof = prof
+        _chk(lib().xee_ensemble_set_profiles(self._h, prof["ra"], prof["za"], prof["rcuva"], prof["rho"],
+                                             prof["exner"], float(prof["dr"]), float(prof["dz"])))
+
+    def upload(self, field, arr, first=0):
+        arr = _a(arr)
+        shp = self._shape(field)
+        if arr.ndim == 2:
+            arr = arr[None]
+        assert arr.shape[1:] == shp, (field, arr.shape, shp)
+        _chk(lib().xee_ensemble_upload(self._h, FIELDS[field], first, arr.shape[0], arr))
+
+    def download(self, field, first=0, count=None):
+        count = self.members - first if count is None else count
+        out = np.zeros((count,) + self._shape(field), np.float32)
+        _chk(lib().xee_ensemble_download(self._h, FIELDS[field], first, count, out))
+        return out
+
+    def device_plane(self, field):
+        """-> (device pointer, pitch, member_stride, n1, n2) for in-place fills by a GPU producer."""
+        p, pitch, ms, n1, n2 = C.c_void_p(), C.c_int(), C.c_size_t(), C.c_int(), C.c_int()
+        _chk(lib().xee_ensemble_device_plane(self._h, FIELDS[field], C.byref(p), C.byref(pitch), C.byref(ms),
+                                             C.byref(n1), C.byref(n2)))
+        return p.value, pitch.value, ms.value, n1.value, n2.value
+
+    def forcing_from_B(self):
+        _chk(lib().xee_ensemble_forcing_from_B(self._h))
+
+    def assemble(self, variant):
+        _chk(lib().xee_ensemble_assemble(self._h, variant))
+
+    def solve(self, max_iter, r1, r2, alpha, check_step=100, converge_time=10, lost_rate=5, flags=0):
+        _chk(lib().xee_ensemble_solve(self._h, int(max_iter), check_step, converge_time, lost_rate,
+                                      float(r1), float(r2), float(alpha), flags))
+        return self.records()
+
+    def cal_eta(self):
+        _chk(lib().xee_ensemble_cal_eta(self._h))
+
+    def cal_uw(self):
+        _chk(lib().xee_ensemble_cal_uw(self._h))
+
+    def ee_scalars(self):
+        _chk(lib().xee_ensemble_ee_scalars(self._h))
+        return self.records()
+
+    def records(self):
+        rec = np.zeros(self.members, RECORD_DTYPE)
+        _chk(lib().xee_ensemble_records(self._h, rec.ctypes.data_as(C.c_void_p)))
+        return rec
+
+    def timing(self):
+        t = Timing()
+        _chk(lib().xee_ensemble_timing(self._h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in Timing._fields_}
+
+    def time_sweeps(self, iters, variant=0, alpha=1.0):
+        ms, n = C.c_double(), C.c_int64()
+        _chk(lib().xee_ensemble_time_sweeps(self._h, iters, variant, float(alpha), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+def diagnose_case(A, B, Cc, bc, forcing=None, *, mode=("DYNAMIC_EFFICIENCY", "CYLINDRICAL", "DENSITY_NORMAL", "BAROTROPIC"),
+                  domain=(0.0, 1.0, 0.0, 1.0), r1=5e-3, r2=5e-3, max_iter=100000, alpha=1.0, flags=0, Q=None):
+    """Host-side mirror of the reference driver for a batch of cases sharing one grid:
+    src/diagnose/initialize-variables.f90:33-95 + diagnose.f90:2-55, on the GPU through the
+    ensemble API.  A, B, Cc, bc (and forcing, Q) are (members, nz, nr) or (nz, nr)."""
+    A, B, Cc, bc = (_a(x)[None] if np.ndim(x) == 2 else _a(x) for x in (A, B, Cc, bc))
+    members, nz, nr = A.shape
+    geometry = 0 if mode[1] == "CYLINDRICAL" else 1
+    dens = 0 if mode[2] == "DENSITY_NORMAL" else 1
+    prof = profiles(nr, nz, geometry, dens, domain)
+    out = {"profiles": prof}
+    with Ensemble(nr, nz, members) as ens:
+        ens.set_profiles(prof)
+        ens.upload("A", A); ens.upload("B", B); ens.upload("C", Cc); ens.upload("BC_INIT", bc)
+        if mode[0] == "DYNAMIC_EFFICIENCY":
+            ens.forcing_from_B()                                   # initialize-variables.f90:41
+        elif mode[0] == "SECONDARY_CIRCULATION":
+            ens.upload("FORCING", _a(forcing)[None] if np.ndim(forcing) == 2 else _a(forcing))
+        else:
+            ens.upload("FORCING", np.zeros_like(A))                # quirk 13: zero RHS
+        if Q is not None:
+            ens.upload("Q", _a(Q)[None] if np.ndim(Q) == 2 else _a(Q))
+        variants = {"BAROTROPIC": [("BAROTROPIC", BAROTROPIC)], "BAROCLINIC": [("BAROCLINIC", BAROCLINIC)],
+                    "BARO_ALL": [("BAROTROPIC", BAROTROPIC), ("BAROCLINIC", BAROCLINIC)]}[mode[3]]
+        for name, v in variants:
+            ens.assemble(v)                                        # K1 + cal_coe, diagnose.f90:6-7,33-34
+            if "solver" not in out:
+                out["solver"] = (ens.download("SOLVER_A"), ens.download("SOLVER_B"), ens.download("SOLVER_C"))
+            rec = ens.solve(max_iter, r1, r2, alpha, flags=flags)  # diagnose.f90:9-15
+            res = {"psi": ens.download("PSI"), "iters": rec["iters"].copy(), "err": rec["err_bits"].copy(),
+                   "r1": rec["err_now"].copy(), "r2": rec["ratio"].copy(), "timing": ens.timing()}
+            if mode[0] == "DYNAMIC_EFFICIENCY":
+                ens.cal_eta()
+                res["eta"] = ens.download("ETA")
+                if Q is not None:
+                    rec = ens.ee_scalars()
+                    res["sum_Q"], res["sum_Qeta"], res["efficiency"] = rec["sum_Q"].copy(), rec["sum_Qeta"].copy(), rec["efficiency"].copy()
+            elif mode[0] == "SECONDARY_CIRCULATION":
+                ens.cal_uw()
+                res["u"], res["w"] = ens.download("U"), ens.download("W")
+            out[name] = res
+    return out
