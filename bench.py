@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- diagnosed cases/s of the elliptic-solve + EE-diagnostic hot path on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A *step* is one pass of the hot path over this rank's batch of synthetic cases, inputs already
+resident in HBM:   f = -B  ->  solver coefficients (K1)  ->  cal_coe (K2)  ->  solve_elliptic
+(K3+K4, fixed-work protocol of SURVEY.md 8d: r1=1e-8, r2 off, alpha=1, max_iter=100,000, check
+every 100)  ->  cal_eta (K5)  ->  EE scalars (K8)  ->  gather of the 128-byte case records over
+RCCL when N>1.  Cases are independent, so ranks share nothing but that gather (weak scaling:
+--members cases per GPU; 32 x 8 GPUs is the 256-member ensemble of BASELINE.json configs[2]).
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (the Jacobi sweep) with the
+ALGORITHMIC byte count of SURVEY.md 8(d) -- 48 B per interior point per iteration -- over the device
+time of the sweep launches, measured with HIP events on the stream they run on (inside libxee's
+solve driver, xee_timing_t.sweep_ms).  `cpu_baseline` times the reference's own solve_elliptic
+(oracle/_ref/libref_elliptic.so, built from the reference sources with amdflang -O2) -- or, if that
+file is absent, the oracle's reference-loop-order port -- on ONE host core for a bounded sample.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+BYTES_PER_POINT_ITER = 48.0  # 9 coe + f + psi read, psi' written
+
+
+def member_fields(nr, nz, m):
+    """SURVEY.md 8d synthetic member m (float64 math, cast to float32)."""
+    r = np.linspace(0.0, 1.0, nr)
+    z = np.linspace(0.0, 1.0, nz)
+    B = 1e-2 * np.sin(2.0 * np.pi * (1 + m % 4) * r)[None, :] * np.sin(np.pi * (1 + m % 5) * z)[:, None]
+    if m > 0:
+        B = B + 1e-4 * np.random.default_rng(20140911 + m).uniform(-1.0, 1.0, size=(nz, nr))
+    one = np.ones((nz, nr), np.float32)
+    rb = 0.5 * (r[1:] + r[:-1])[None, :]
+    zb = 0.5 * (z[1:] + z[:-1])[:, None]
+    Q = np.exp(-((rb - 0.3) / 0.1) ** 2 - ((zb - 0.5) / 0.2) ** 2) * (1.0 + 0.01 * (m % 7))
+    return one, B.astype(np.float32), one, np.zeros((nz, nr), np.float32), Q.astype(np.float32)
+
+
+def cpu_baseline(nr, nz, max_iter, sample_iters):
+    """Reference CPU path on one host core: solve_elliptic for `sample_iters` iterations of one case
+    of the same workload, scaled linearly to max_iter (per-iteration cost is constant)."""
+    import orchelp as H
+    A, B, Cc, bc = H.test1_inputs(nr, nz)
+    prof = H.profiles(nr, nz)
+    sA, sB, sC = H.solver_coefficients(A, B, Cc, prof["rcuva"], prof["rho"])
+    coe = H.cal_coe(sA, np.zeros_like(sB), sC, prof["dr"], prof["dz"], nr, nz)
+    f = (-B).astype(np.float32)
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    saved = os.dup(1)
+    sys.stdout.flush()
+    os.dup2(devnull, 1)                      # the reference prints "Elliptic Tools: ..." per call
+    try:
+        if H.have_ref():
+            kind = "reference"
+            t0 = time.perf_counter()
+            H.ref_solve(bc, coe, f, sample_iters, 1e-8, -1.0, 1.0)
+            dt = time.perf_counter() - t0
+        else:
+            kind = "port"
+            t0 = time.perf_counter()
+            H.solve(bc, coe, f, sample_iters, 1e-8, -1.0, 1.0, reforder=True)
+            dt = time.perf_counter() - t0
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(devnull)
+        os.close(saved)
+    per_iter = dt / sample_iters
+    return {"value": 1.0 / (per_iter * max_iter), "unit": "cases/s", "cores": 1, "kind": kind,
+            "sample": f"solve_elliptic on one {nr}x{nz} case, {sample_iters} iterations in {dt:.2f} s "
+                      f"({per_iter * 1e3:.2f} ms/iteration), scaled linearly to {max_iter} iterations",
+            "ms_per_iteration": per_iter * 1e3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--members", type=int, default=32, help="cases per GPU (weak scaling)")
+    ap.add_argument("--nr", type=int, default=1024)
+    ap.add_argument("--nz", type=int, default=512)
+    ap.add_argument("--max-iter", type=int, default=100000)
+    ap.add_argument("--cpu-sample-iters", type=int, default=500)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import xee_pkg
+    xee = xee_pkg.load()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available() or xee.device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: libxee has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    nr, nz, M = args.nr, args.nz, args.members
+    prof = xee.profiles(nr, nz, 0, 0, (0.0, 1.0, 0.0, 1.0))
+    ens = xee.Ensemble(nr, nz, M, device=local_rank)
+    ens.set_profiles(prof)
+    ens.set_case_ids(rank * M)
+    for m in range(M):                         # inputs resident in HBM before the timed region
+        A, B, Cc, bc, Q = member_fields(nr, nz, rank * M + m)
+        for name, arr in (("A", A), ("B", B), ("C", Cc), ("BC_INIT", bc), ("Q", Q)):
+            ens.upload(name, arr, first=m)
+
+    rec_dev = torch.empty((M, 128), dtype=torch.uint8, device="cuda")
+    gathered = torch.empty((world * M, 128), dtype=torch.uint8, device="cuda") if world > 1 else None
+
+    def step():
+        ens.forcing_from_B()                   # A7
+        ens.assemble(xee.BAROTROPIC)           # K1 + K2
+        ens.solve(args.max_iter, 1e-8, -1.0, 1.0, check_step=100, converge_time=10, lost_rate=5)   # K3 + K4
+        ens.cal_eta()                          # K5
+        rec = ens.ee_scalars()                 # K8
+        if world > 1:                          # the one collective of the path: scalar records over RCCL
+            rec_dev.copy_(torch.from_numpy(rec.view(np.uint8).reshape(M, 128)))
+            dist.all_gather_into_tensor(gathered, rec_dev)
+        return rec
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    sweep_ms = 0.0
+    iters = 0
+    launches = 0
+    for _ in range(args.steps):
+        rec = step()
+        t = ens.timing()
+        sweep_ms += t["sweep_ms"]
+        iters += t["iterations"]
+        launches += t["sweep_launches"]
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        cases = world * M * args.steps
+        interior = (nr - 2) * (nz - 2)
+        alg_bytes = BYTES_PER_POINT_ITER * interior * M * iters        # this rank, all timed steps
+        achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
+        out = {
+            "metric": "diagnosed cases/s (1024x512 r-z grid, SOR to 1e-8)",
+            "value": cases / dt, "unit": "cases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{M} independent {nr}x{nz} cases per GPU (x8 GPUs = the 256-member ensemble of "
+                                   f"configs[2]); each case = configs[1]: K1+K2+solve_elliptic(r1=1e-8, r2 off, alpha=1, "
+                                   f"max_iter={args.max_iter}, check every 100)+cal_eta+EE scalars",
+                       "nr": nr, "nz": nz, "members_per_gpu": M, "max_iter": args.max_iter,
+                       "solver": "damped Jacobi, bit-identical to the reference (SURVEY.md finding 1)",
+                       "parallelism": f"ensemble-dp{world}"},
+            "iterations_per_s": world * M * iters / dt,
+            "point_updates_per_s": world * M * iters * interior / dt,
+            "all_cases_ran_to_max_iter": bool(np.all(rec["iters"] == args.max_iter)),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_sweep_stream (Jacobi sweep)",
+                         "algorithmic_bytes_per_launch": alg_bytes / max(launches, 1),
+                         "avg_launch_us": sweep_ms * 1e3 / max(launches, 1), "launches": launches},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(nr, nz, args.max_iter, args.cpu_sample_iters)
+        print(json.dumps(out), flush=True)
+    ens.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -247,10 +247,28 @@ __global__ __launch_bounds__(256) void k_seqsum(Grid g, const float* __restrict_
             const int nc = min(TC, ncols - t * TC);
             for (int cidx = 0; cidx < nc; ++cidx) {
                 const float* col = buf + cidx * colstride;
+                // the add chain is the critical path: keep 32 LDS values in flight ahead of it
+                float4 q[8];
                 int r = 0;
+                if (nrows >= 32) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) q[k] = *reinterpret_cast<const float4*>(col + 4 * k);
+                    for (; r + 64 <= nrows; r += 32) {
+                        float4 n[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) n[k] = *reinterpret_cast<const float4*>(col + r + 32 + 4 * k);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) { s = s + q[k].x; s = s + q[k].y; s = s + q[k].z; s = s + q[k].w; }
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) q[k] = n[k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { s = s + q[k].x; s = s + q[k].y; s = s + q[k].z; s = s + q[k].w; }
+                    r += 32;
+                }
                 for (; r + 4 <= nrows; r += 4) {
-                    const float4 q = *reinterpret_cast<const float4*>(col + r);
-                    s = s + q.x; s = s + q.y; s = s + q.z; s = s + q.w;
+                    const float4 v = *reinterpret_cast<const float4*>(col + r);
+                    s = s + v.x; s = s + v.y; s = s + v.z; s = s + v.w;
                 }
                 for (; r < nrows; ++r) s = s + col[r];
             }
