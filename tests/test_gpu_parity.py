@@ -214,3 +214,32 @@ def test_ee_scalars_ensemble():
         assert out["sum_Q"][m].tobytes() == sq.tobytes()
         assert out["sum_Qeta"][m].tobytes() == sqe.tobytes()
         assert out["efficiency"][m].tobytes() == np.float32(sqe / sq).tobytes()
+
+
+# ---- temporally blocked sweep (K3-TB) ----------------------------------------------------------
+
+@pytest.mark.parametrize("T", [2, 3, 5, 8, 13, 16])
+@pytest.mark.parametrize("nr,nz,iters", [(200, 120, 437), (64, 48, 250), (1024, 512, 203), (130, 300, 301)])
+def test_temporal_blocking_is_bit_identical(T, nr, nz, iters, monkeypatch):
+    """T iterations per launch (overlapped tiles, register-resident coefficients) must reproduce the
+    oracle bit for bit for every T, incl. tiles cut by the domain edge, ragged last tiles and a
+    check iteration (multiple of 100) that falls inside a launch."""
+    monkeypatch.setenv("XEE_TB_T", str(T))
+    A, B, Cc, bc = H.rich_inputs(nr, nz, seed=T + nr)
+    cfg = dict(mode=("DYNAMIC_EFFICIENCY", "CYLINDRICAL", "DENSITY_NORMAL", "BAROCLINIC"),
+               domain=(0.0, 2.0e5, 0.0, 1.5e4), r1=1e-8, r2=-1.0, max_iter=iters, alpha=0.9)
+    got = xee.diagnose_case(A, B, Cc, bc, **cfg)["BAROCLINIC"]
+    want = H.diagnose_case(A, B, Cc, bc, **cfg)["BAROCLINIC"]
+    assert int(got["iters"][0]) == want["iters"] == iters
+    assert biteq(got["psi"][0], want["psi"])
+    assert got["r1"][0].tobytes() == want["r1"].tobytes() and got["r2"][0].tobytes() == want["r2"].tobytes()
+
+
+def test_single_step_flag_equals_blocked_path():
+    nr, nz = 300, 200
+    A, B, Cc, bc = H.rich_inputs(nr, nz, seed=77)
+    cfg = dict(r1=1e-8, r2=-1.0, max_iter=333, alpha=1.0)
+    a = xee.diagnose_case(A, B, Cc, bc, **cfg)["BAROTROPIC"]
+    b = xee.diagnose_case(A, B, Cc, bc, flags=1, **cfg)["BAROTROPIC"]      # XEE_SOLVE_SINGLE_STEP
+    assert biteq(a["psi"], b["psi"]) and a["r1"].tobytes() == b["r1"].tobytes()
+    assert a["timing"]["sweep_launches"] < b["timing"]["sweep_launches"] == 333

@@ -7,6 +7,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -73,6 +74,7 @@ struct xee_ensemble {
     std::vector<xee_case_record_t> rec;
     xee_timing_t timing{};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int tb_T = 8;   // iterations per temporally blocked launch (XEE_TB_T overrides)
 };
 
 namespace {
@@ -234,6 +236,7 @@ int xee_ensemble_create(xee_ensemble_t** out, int nr, int nz, int n_members, int
     e->g.pitch = ((nr + 63) / 64) * 64;
     e->g.members = n_members;
     e->g.plane = (size_t)e->g.pitch * nz;
+    if (const char* tv = getenv("XEE_TB_T")) { int t = atoi(tv); if (t >= 1 && t <= tb_max_T()) e->tb_T = t; }
     int st = XEE_OK;
     auto guard = [&](int s) { if (st == XEE_OK) st = s; };
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return fail(XEE_ERR_HIP, "hipStreamCreate failed"); }
@@ -412,21 +415,32 @@ int xee_ensemble_solve(xee_ensemble_t* e, int max_iter, int check_step, int conv
     if (flags & XEE_SOLVE_KEEP_PSI) launch_copy2(g, e->psi[e->cur], e->psi[e->cur ^ 1], nullptr, s);
     else { launch_copy2(g, e->bc, e->psi[0], e->psi[1], s); e->cur = 0; }
     launch_state_init(g, e->st, s);
-    const int start = e->cur;
+    int cur = e->cur;                                   // plane holding the newest iterate
+    std::vector<int> final_buf(g.members, cur);        // plane a member's result was written to
+    std::vector<char> was_active(g.members, 1);
+    const int tb_T = (flags & XEE_SOLVE_SINGLE_STEP) ? 1 : e->tb_T;
 
     e->timing = xee_timing_t{};
     HIPCHK(hipEventRecord(e->ev[0], s));
     bool block_open = false;
     int cnt = 0;
     bool all_done = (max_iter == 0);
-    for (cnt = 1; cnt <= max_iter && !all_done; ++cnt) {
-        const bool check = (cnt % cs) == 0;
-        if (!block_open) { HIPCHK(hipEventRecord(e->ev[2], s)); block_open = true; }
-        const int src = (start + cnt - 1) & 1;
-        launch_sweep(g, e->psi[src], e->psi[src ^ 1], e->coe, e->f, check ? e->res : nullptr, e->st, alpha, s);
-        e->timing.sweep_launches += 1;
-        e->timing.iterations += 1;
+    while (cnt < max_iter && !all_done) {
+        // iterations until the next residual check (or the end): one launch does up to tb_T of them
+        const int next_check = (cnt / cs + 1) * cs;
+        const int target = next_check < max_iter ? next_check : max_iter;
+        const int n = (target - cnt) < tb_T ? (target - cnt) : tb_T;
+        cnt += n;
+        const bool check = cnt == next_check;
         const bool last = cnt == max_iter;
+        if (!block_open) { HIPCHK(hipEventRecord(e->ev[2], s)); block_open = true; }
+        if (n == 1)
+            launch_sweep(g, e->psi[cur], e->psi[cur ^ 1], e->coe, e->f, check ? e->res : nullptr, e->st, alpha, s);
+        else
+            launch_sweep_tb(g, e->psi[cur], e->psi[cur ^ 1], e->coe, e->f, check ? e->res : nullptr, e->st, alpha, n, s);
+        cur ^= 1;
+        e->timing.sweep_launches += 1;
+        e->timing.iterations += n;
         if (check) {
             HIPCHK(hipEventRecord(e->ev[3], s));
             launch_seqsum(g, e->res, 1, g.nx - 1, 1, g.ny - 1, true, e->sums, e->st, s);
@@ -448,7 +462,11 @@ int xee_ensemble_solve(xee_ensemble_t* e, int max_iter, int check_step, int conv
                 block_open = false;
             }
             all_done = true;
-            for (int m = 0; m < g.members; ++m) if (e->st_host[m].active) { all_done = false; break; }
+            for (int m = 0; m < g.members; ++m) {
+                if (was_active[m]) final_buf[m] = cur;          // it took part in the launch just done
+                was_active[m] = (char)e->st_host[m].active;
+                if (e->st_host[m].active) all_done = false;
+            }
         }
     }
     HIPCHK(hipEventRecord(e->ev[1], s));
@@ -460,19 +478,15 @@ int xee_ensemble_solve(xee_ensemble_t* e, int max_iter, int check_step, int conv
     HIPCHK(hipEventElapsedTime(&ms, e->ev[0], e->ev[1]));
     e->timing.solve_ms = ms;
 
-    // :259-264  every member's result into one plane.  Iteration k wrote psi[(start+k)&1]; the
-    // planes of a stopped member are never touched again.
-    int last_iter = 0;
-    for (int m = 0; m < g.members; ++m) if (e->st_host[m].iters > last_iter) last_iter = e->st_host[m].iters;
-    const int fin = (start + last_iter) & 1;
+    // :259-264  every member's result into one plane.  A stopped member's planes are never touched
+    // again, so its result still sits in the plane its last launch wrote.
     for (int m = 0; m < g.members; ++m) {
-        const int mine = (start + e->st_host[m].iters) & 1;
-        if (mine != fin)
-            HIPCHK(hipMemcpyAsync(e->psi[fin] + (size_t)m * g.plane, e->psi[mine] + (size_t)m * g.plane,
+        if (final_buf[m] != cur)
+            HIPCHK(hipMemcpyAsync(e->psi[cur] + (size_t)m * g.plane, e->psi[final_buf[m]] + (size_t)m * g.plane,
                                   sizeof(float) * g.plane, hipMemcpyDeviceToDevice, s));
     }
     HIPCHK(hipStreamSynchronize(s));
-    e->cur = fin;
+    e->cur = cur;
     for (int m = 0; m < g.members; ++m) {
         xee_case_record_t& r = e->rec[m];
         r.iters = e->st_host[m].iters;
@@ -547,23 +561,29 @@ int xee_ensemble_time_sweeps(xee_ensemble_t* e, int iters, int variant, float al
                              int64_t* launches)
 {
     XCHK(use(e));
-    if (iters < 1 || variant != 0) return fail(XEE_ERR_INVALID_ARGUMENT, "iters >= 1 and variant 0 (streaming) only");
+    if (iters < 1 || (variant != 0 && variant != 1)) return fail(XEE_ERR_INVALID_ARGUMENT, "iters >= 1, variant 0 (streaming) or 1 (temporally blocked)");
     const Grid& g = e->g;
     hipStream_t s = e->stream;
     launch_state_init(g, e->st, s);
+    int64_t nl = 0;
+    int cur = e->cur;
     HIPCHK(hipEventRecord(e->ev[0], s));
-    for (int k = 0; k < iters; ++k) {
-        const int src = (e->cur + k) & 1;
-        launch_sweep(g, e->psi[src], e->psi[src ^ 1], e->coe, e->f, nullptr, e->st, alpha, s);
+    for (int k = 0; k < iters;) {
+        const int n = variant == 0 ? 1 : ((iters - k) < e->tb_T ? (iters - k) : e->tb_T);
+        if (n == 1) launch_sweep(g, e->psi[cur], e->psi[cur ^ 1], e->coe, e->f, nullptr, e->st, alpha, s);
+        else launch_sweep_tb(g, e->psi[cur], e->psi[cur ^ 1], e->coe, e->f, nullptr, e->st, alpha, n, s);
+        cur ^= 1;
+        k += n;
+        ++nl;
     }
     HIPCHK(hipEventRecord(e->ev[1], s));
     HIPCHK(hipStreamSynchronize(s));
     XCHK(check_launch("time_sweeps"));
-    e->cur = (e->cur + iters) & 1;
+    e->cur = cur;
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, e->ev[0], e->ev[1]));
     if (elapsed_ms) *elapsed_ms = ms;
-    if (launches) *launches = iters;
+    if (launches) *launches = nl;
     return XEE_OK;
 }
 

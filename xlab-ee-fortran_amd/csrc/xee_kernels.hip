@@ -205,6 +205,105 @@ __global__ __launch_bounds__(256) void k_sweep_stream(Grid g, const float* __res
 }
 
 // =============================================================================================
+// K3-TB  T damped-Jacobi iterations per launch, temporally blocked (bit-identical: Jacobi reads only
+//     the previous iterate, so any tiling that feeds each point the same operands in the same
+//     per-point order gives the same bits).
+//     Workgroup = NW waves stacked in z; wave = 64 columns (lanes) x R rows held in REGISTERS
+//     together with their 9 coefficients and f -- loaded from HBM once per launch, used T times.
+//     i+-1 neighbours: DPP whole-wave shifts (the tile's outer columns become invalid, one per
+//     iteration and side); j+-1 across waves: the two boundary rows of each wave go through LDS
+//     (double-buffered by iteration parity -> one barrier per iteration).  Tiles overlap by 2T and
+//     only the region whose dependency cone stayed inside the tile (or hit the Dirichlet rim) is
+//     stored.  HBM bytes per useful point-iteration ~ 48 / (T * tile efficiency).
+// =============================================================================================
+template <int NW, int R, bool WRITE_R>
+__global__ __launch_bounds__(NW * 64) void k_sweep_tb(Grid g, const float* __restrict__ psi_in,
+        float* __restrict__ psi_out, const float* __restrict__ coe, const float* __restrict__ f,
+        float* __restrict__ res, const MemberState* __restrict__ st, float alpha, int T)
+{
+    __shared__ float edge[2][2][NW][64];
+    const int m = blockIdx.z;
+    if (st && !st[m].active) return;                      // workgroup-uniform
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    constexpr int H = NW * R;
+    const int x0 = (int)blockIdx.x * (64 - 2 * T) - T;    // tile origin (may lie outside the domain)
+    const int y0 = (int)blockIdx.y * (H - 2 * T) - T;
+    const int gx = x0 + lane;
+    const int gy0 = y0 + w * R;
+    const bool col_in = gx >= 0 && gx < g.nx;
+    const bool col_int = gx >= 1 && gx <= g.nx - 2;
+    const size_t mo = (size_t)m * g.plane;
+    const size_t ks = (size_t)g.members * g.plane;
+
+    float c[9][R], ff[R], p[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int gy = gy0 + r;
+        const bool in = col_in && gy >= 0 && gy < g.ny;
+        const bool interior = col_int && gy >= 1 && gy <= g.ny - 2;
+        const size_t o = mo + (size_t)(in ? gy : 0) * g.pitch + (in ? gx : 0);
+        p[r] = in ? psi_in[o] : 0.0f;
+        ff[r] = interior ? f[o] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) c[k][r] = interior ? coe[k * ks + o] : 0.0f;
+    }
+
+    // validity after T iterations: dependency cone inside the tile, or cut by the domain edge (rim
+    // and outside never change and nothing inside depends on what lies beyond them)
+    const bool vx = (lane >= T || x0 <= 0) && (lane < 64 - T || x0 + 63 >= g.nx - 1);
+    for (int t = 0; t < T; ++t) {
+        const int par = t & 1;
+        edge[par][0][w][lane] = p[R - 1];                 // my top row, for the wave above
+        edge[par][1][w][lane] = p[0];                     // my bottom row, for the wave below
+        __syncthreads();
+        const float below = (w > 0) ? edge[par][0][w - 1][lane] : 0.0f;
+        const float above = (w < NW - 1) ? edge[par][1][w + 1][lane] : 0.0f;
+        float om = below, oml = wave_shr1(0.0f, om), omr = wave_shl1(0.0f, om);
+        float oc = p[0], ocl = wave_shr1(0.0f, oc), ocr = wave_shl1(0.0f, oc);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float on = (r + 1 < R) ? p[r + 1] : above;
+            const float onl = wave_shr1(0.0f, on), onr = wave_shl1(0.0f, on);
+            float Rv = c[0][r] * onl;                     // elliptic_tools.f90:77-85, left to right
+            Rv = Rv + c[1][r] * on;
+            Rv = Rv + c[2][r] * onr;
+            Rv = Rv + c[3][r] * ocl;
+            Rv = Rv + c[4][r] * oc;
+            Rv = Rv + c[5][r] * ocr;
+            Rv = Rv + c[6][r] * oml;
+            Rv = Rv + c[7][r] * om;
+            Rv = Rv + c[8][r] * omr;
+            Rv = Rv - ff[r];                              // :190
+            const float upd = oc + alpha * Rv / (-c[4][r]);   // :238
+            const int gy = gy0 + r;
+            const bool interior = col_int && gy >= 1 && gy <= g.ny - 2;
+            p[r] = interior ? upd : oc;
+            if (WRITE_R && t == T - 1) {                  // residual of the launch's last iteration
+                const int ly = w * R + r;
+                const bool vy = (ly >= T || y0 <= 0) && (ly < H - T || y0 + H - 1 >= g.ny - 1);
+                if (vx && vy && interior) res[mo + (size_t)gy * g.pitch + gx] = Rv;
+            }
+            om = oc; oml = ocl; omr = ocr;
+            oc = on; ocl = onl; ocr = onr;
+        }
+    }
+
+    // store what is provably exact after T iterations
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int ly = w * R + r;
+        const int gy = gy0 + r;
+        const bool vy = (ly >= T || y0 <= 0) && (ly < H - T || y0 + H - 1 >= g.ny - 1);
+        const bool interior = col_int && gy >= 1 && gy <= g.ny - 2;
+        if (vx && vy && interior) {
+            const size_t o = mo + (size_t)gy * g.pitch + gx;
+            psi_out[o] = p[r];
+        }
+    }
+}
+
+// =============================================================================================
 // K4  order-exact residual norm / domain integrals: sequential fp32 sum, i outer / j inner
 //     (elliptic_tools.f90:193-199; old-diagnose/diagnose.f90:1035-1046).  One workgroup per member:
 //     waves 1-3 stage the next TC columns transposed (and squared) into LDS while lane 0 of wave 0
@@ -557,6 +656,26 @@ void launch_sweep(const Grid& g, const float* psi_in, float* psi_out, const floa
     else if (blocks(4) >= 2048) launch_sweep_rj<4>(g, psi_in, psi_out, coe, f, res, st, alpha, s);
     else if (blocks(2) >= 1024) launch_sweep_rj<2>(g, psi_in, psi_out, coe, f, res, st, alpha, s);
     else launch_sweep_rj<1>(g, psi_in, psi_out, coe, f, res, st, alpha, s);
+}
+
+template <int NW, int R>
+static void launch_tb_cfg(const Grid& g, const float* psi_in, float* psi_out, const float* coe, const float* f,
+                          float* res, const MemberState* st, float alpha, int T, hipStream_t s)
+{
+    constexpr int H = NW * R;
+    dim3 grid((g.nx - 1 + (64 - 2 * T) - 1) / (64 - 2 * T), (g.ny - 1 + (H - 2 * T) - 1) / (H - 2 * T), g.members);
+    if (res)
+        hipLaunchKernelGGL((k_sweep_tb<NW, R, true>), grid, dim3(NW * 64), 0, s, g, psi_in, psi_out, coe, f, res, st, alpha, T);
+    else
+        hipLaunchKernelGGL((k_sweep_tb<NW, R, false>), grid, dim3(NW * 64), 0, s, g, psi_in, psi_out, coe, f, res, st, alpha, T);
+}
+
+int tb_max_T() { return 16; }
+
+void launch_sweep_tb(const Grid& g, const float* psi_in, float* psi_out, const float* coe, const float* f,
+                     float* res, const MemberState* st, float alpha, int T, hipStream_t s)
+{
+    launch_tb_cfg<8, 16>(g, psi_in, psi_out, coe, f, res, st, alpha, T, s);
 }
 
 static void seqsum_shape(const Grid& g, int nrows, int* TC, int* colstride)
