@@ -126,8 +126,7 @@ def main():
         for name, arr in (("A", A), ("B", B), ("C", Cc), ("BC_INIT", bc), ("Q", Q)):
             ens.upload(name, arr, first=m)
 
-    rec_dev = torch.empty((M, 128), dtype=torch.uint8, device="cuda")
-    gathered = torch.empty((world * M, 128), dtype=torch.uint8, device="cuda") if world > 1 else None
+    from xlab_ee_fortran_amd import ensemble_dp as dp
 
     def step():
         ens.forcing_from_B()                   # A7
@@ -136,8 +135,7 @@ def main():
         ens.cal_eta()                          # K5
         rec = ens.ee_scalars()                 # K8
         if world > 1:                          # the one collective of the path: scalar records over RCCL
-            rec_dev.copy_(torch.from_numpy(rec.view(np.uint8).reshape(M, 128)))
-            dist.all_gather_into_tensor(gathered, rec_dev)
+            rec = dp.gather_records(rec, world * M, world, rank, device="cuda")
         return rec
 
     def fence():
@@ -183,7 +181,7 @@ def main():
                        "parallelism": f"ensemble-dp{world}"},
             "iterations_per_s": world * M * iters / dt,
             "point_updates_per_s": world * M * iters * interior / dt,
-            "all_cases_ran_to_max_iter": bool(np.all(rec["iters"] == args.max_iter)),
+            "all_cases_ran_to_max_iter": bool(len(rec) == world * M and np.all(rec["iters"] == args.max_iter)),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "k_sweep_stream (Jacobi sweep)",

@@ -67,7 +67,10 @@ int xee_do_elliptic(const float *psi, const float *coe, float *outdat, int nx, i
 /* replaces solve_elliptic, elliptic_tools.f90:93-265.  *max_iter, *strategy_r1, *strategy_r2 and
  * *err are overwritten with iterations used, final RMS residual, final |ratio| and the error
  * bitmask (:253).  `workspace` is scratch (unspecified content on return, as for the reference's
- * callers).  debug: 1/2 echo the inputs, 2 also prints the per-check trace (:146-158,:202-204). */
+ * callers).  debug: 1/2 echo the inputs, 2 also prints the per-check trace (:146-158,:202-204).
+ * OR-ing XEE_DEBUG_NO_JUDGE into debug suppresses the judge_error text of :254 for hosts that print
+ * it through their own I/O unit (the Fortran shim does, to keep its stdout ordering). */
+#define XEE_DEBUG_NO_JUDGE 0x100
 int xee_solve_elliptic(int *max_iter, int check_step, int converge_time, int lost_rate,
                        float *strategy_r1, float *strategy_r2, float alpha,
                        float *dat, const float *coe, const float *f, float *workspace,

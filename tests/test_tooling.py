@@ -1,0 +1,75 @@
+"""CPU tests of the config/result tooling: the diag.txt writer keeps small
+tolerances and follows the reference's line order; the efficiency.txt reader returns XEffReader's keys
+on the reference's own sample output (data as printed by the legacy program)."""
+import numpy as np
+
+import xee_pkg
+
+xee = xee_pkg.load()
+from xlab_ee_fortran_amd import xee_tools as T  # noqa: E402
+
+# efficiency.txt of the legacy program on a 64x48 TENDENCY/BAROTROPIC case
+LEGACY_SAMPLE = """ Time elapsed (sec)                          :  .5942564
+ sum Q                                       :  5.0221204E-02
+ sum dtheta_dt                               :  5.0052203E-05
+ Local heat response (sum Q / sum dtheta_dt) :  9.966348E-04
+ # Boundary efficiency
+ # Internal efficiency
+ eta [L(B=0)    = dB]     wo/ boundary :  1.1498614E-08 ,  2.2895933E-07
+ eta [L(B=0)    = B0]     wo/ boundary :  2.0280158E-10 ,  4.0381662E-09
+ # Decomposition sum
+ etaQ [L(B=0)    = J F] w/  boundary :  1.1701415E-08 ,  2.329975E-07
+ # wtheta integral
+ wtheta [L(B=0)    = J F] w/  boundary :  1.1552168E-08 ,  2.300257E-07
+"""
+
+
+def test_read_efficiency_keys_on_legacy_sample(tmp_path):
+    p = tmp_path / "efficiency.txt"
+    p.write_text(LEGACY_SAMPLE)
+    eff = T.read_efficiency(str(p))
+    assert set(eff) == {"semi_internal", "semi_cb1", "internal", "wtheta", "local_response", "semi_total"}
+    assert eff["internal"] == 2.2895933e-07 + 4.0381662e-09
+    assert eff["semi_internal"] == eff["internal"]
+    assert eff["wtheta"] == 2.300257e-07
+    assert eff["local_response"] == 9.966348e-04
+    assert eff["semi_total"] == eff["semi_internal"] + eff["semi_cb1"]
+    raw = T.read_efficiency_raw(str(p))
+    assert raw["sum Q"] == (5.0221204e-02, None)
+
+
+def test_diag_config_round_trip_keeps_small_tolerances(tmp_path):
+    s = T.empty_setting()
+    s["RESIDUE_CRITERIA"] = {"absolute": 1e-8, "relative": -1.0, "alpha": 1.0, "max_iteration": 100000}
+    s["POINTS"] = {"horizontal": 1024, "vertical": 512}
+    s["Q_FILE"] = "Q.bin"
+    p = tmp_path / "diag.txt"
+    T.write_diag_config(str(p), s)
+    lines = [ln.split("//")[0].strip() for ln in p.read_text().splitlines()]
+    assert lines[0] == "DYNAMIC_EFFICIENCY-CYLINDRICAL-DENSITY_NORMAL-BAROTROPIC"
+    assert [float(v) for v in lines[1].split()] == [0.0, 100.0, 0.0, 100.0]
+    assert lines[2].split() == ["1024", "512"]
+    assert lines[3:9] == [".", ".", "A.bin", "B.bin", "C.bin", "bc_init.bin"]
+    r1, r2, mi, al = lines[9].split()
+    assert float(r1) == 1e-8 and float(r2) == -1.0 and int(mi) == 100000 and float(al) == 1.0
+    assert lines[10] == "Q.bin"
+
+
+def test_diag_config_spherical_and_forcing(tmp_path):
+    s = T.empty_setting()
+    s["GEOMETRY"] = "SPHERICAL"
+    s["TYPE"] = "SECONDARY_CIRCULATION"
+    p = tmp_path / "diag.txt"
+    T.write_diag_config(str(p), s)
+    lines = [ln.split("//")[0].strip() for ln in p.read_text().splitlines()]
+    assert len(lines[1].split()) == 3 and float(lines[1].split()[0]) == 6371000.0
+    assert lines[8] == "forcing.bin" and lines[9] == "bc_init.bin"
+
+
+def test_ensemble_member_zero_is_noise_free_and_deterministic():
+    A, B, Cc, bc = T.ensemble_member(64, 48, 0)
+    A2, B2, _, _ = T.ensemble_member(64, 48, 0)
+    assert np.array_equal(B, B2) and np.all(A == 1) and np.all(bc == 0)
+    _, B5, _, _ = T.ensemble_member(64, 48, 5)
+    _, B5b, _, _ = T.ensemble_member(64, 48, 5)
+    assert np.array_equal(B5, B5b) and not np.array_equal(B5, B)

@@ -1,0 +1,158 @@
+! xee_c_api.f90 -- ISO_C_BINDING view of libxee's Tier-2 (ensemble) C-ABI and of xee_profiles
+! (include/xee.h), for Fortran hosts that keep their data on the GPU between the stages of
+! src/diagnose/diagnose.f90 instead of round-tripping through the Tier-1 drop-in calls.
+module xee_c_api
+use, intrinsic :: iso_c_binding
+implicit none
+public
+
+integer(c_int), parameter :: XEE_OK = 0, XEE_ERR_INVALID_CRITERIA = 1
+integer(c_int), parameter :: XEE_BAROTROPIC = 0, XEE_BAROCLINIC = 1
+integer(c_int), parameter :: XEE_F_A = 0, XEE_F_B = 1, XEE_F_C = 2, XEE_F_BC_INIT = 3,          &
+    &   XEE_F_FORCING = 4, XEE_F_PSI = 5, XEE_F_SOLVER_A = 6, XEE_F_SOLVER_B = 7,                &
+    &   XEE_F_SOLVER_C = 8, XEE_F_ETA = 9, XEE_F_U = 10, XEE_F_W = 11, XEE_F_Q = 12
+integer(c_int), parameter :: XEE_SOLVE_DEFAULT = 0, XEE_SOLVE_TRACE = 4
+
+! xee_case_record_t, 128 bytes
+type, bind(C) :: xee_case_record
+    integer(c_int32_t) :: case_id, iters, err_bits, reserved
+    real(c_float)      :: err_now, ratio, sum_Q, sum_Qeta, efficiency
+    real(c_float)      :: scalars(23)
+end type
+
+interface
+    function xee_device_count(n) bind(C, name="xee_device_count") result(st)
+        import :: c_int
+        integer(c_int), intent(out) :: n
+        integer(c_int) :: st
+    end function
+
+    function xee_last_error() bind(C, name="xee_last_error") result(p)
+        import :: c_ptr
+        type(c_ptr) :: p
+    end function
+
+    function xee_profiles(geometry, density_mode, domain, nr, nz, ra, za, rcuva, exner, rho,     &
+        &                 sin_table, dr, dz) bind(C, name="xee_profiles") result(st)
+        import :: c_int, c_float
+        integer(c_int), value :: geometry, density_mode, nr, nz
+        real(c_float), intent(in)  :: domain(*)
+        real(c_float), intent(out) :: ra(*), za(*), rcuva(*), exner(*), rho(*), sin_table(*)
+        real(c_float), intent(out) :: dr, dz
+        integer(c_int) :: st
+    end function
+
+    function xee_ensemble_create(ens, nr, nz, n_members, device) bind(C, name="xee_ensemble_create") result(st)
+        import :: c_int, c_ptr
+        type(c_ptr), intent(out) :: ens
+        integer(c_int), value :: nr, nz, n_members, device
+        integer(c_int) :: st
+    end function
+
+    function xee_ensemble_destroy(ens) bind(C, name="xee_ensemble_destroy") result(st)
+        import :: c_int, c_ptr
+        type(c_ptr), value :: ens
+        integer(c_int) :: st
+    end function
+
+    function xee_ensemble_set_profiles(ens, ra, za, rcuva, rho, exner, dr, dz)                   &
+        &                              bind(C, name="xee_ensemble_set_profiles") result(st)
+        import :: c_int, c_ptr, c_float
+        type(c_ptr), value :: ens
+        real(c_float), intent(in) :: ra(*), za(*), rcuva(*), rho(*), exner(*)
+        real(c_float), value :: dr, dz
+        integer(c_int) :: st
+    end function
+
+    function xee_ensemble_upload(ens, field, first, count, host) bind(C, name="xee_ensemble_upload") result(st)
+        import :: c_int, c_ptr, c_float
+        type(c_ptr), value :: ens
+        integer(c_int), value :: field, first, count
+        real(c_float), intent(in) :: host(*)
+        integer(c_int) :: st
+    end function
+
+    function xee_ensemble_download(ens, field, first, count, host) bind(C, name="xee_ensemble_download") result(st)
+        import :: c_int, c_ptr, c_float
+        type(c_ptr), value :: ens
+        integer(c_int), value :: field, first, count
+        real(c_float), intent(inout) :: host(*)
+        integer(c_int) :: st
+    end function
+
+    function xee_ensemble_forcing_from_B(ens) bind(C, name="xee_ensemble_forcing_from_B") result(st)
+        import :: c_int, c_ptr
+        type(c_ptr), value :: ens
+        integer(c_int) :: st
+    end function
+
+    function xee_ensemble_assemble(ens, variant) bind(C, name="xee_ensemble_assemble") result(st)
+        import :: c_int, c_ptr
+        type(c_ptr), value :: ens
+        integer(c_int), value :: variant
+        integer(c_int) :: st
+    end function
+
+    function xee_ensemble_solve(ens, max_iter, check_step, converge_time, lost_rate, r1, r2,     &
+        &                       alpha, flags) bind(C, name="xee_ensemble_solve") result(st)
+        import :: c_int, c_ptr, c_float
+        type(c_ptr), value :: ens
+        integer(c_int), value :: max_iter, check_step, converge_time, lost_rate, flags
+        real(c_float), value :: r1, r2, alpha
+        integer(c_int) :: st
+    end function
+
+    function xee_ensemble_cal_eta(ens) bind(C, name="xee_ensemble_cal_eta") result(st)
+        import :: c_int, c_ptr
+        type(c_ptr), value :: ens
+        integer(c_int) :: st
+    end function
+
+    function xee_ensemble_cal_uw(ens) bind(C, name="xee_ensemble_cal_uw") result(st)
+        import :: c_int, c_ptr
+        type(c_ptr), value :: ens
+        integer(c_int) :: st
+    end function
+
+    function xee_ensemble_ee_scalars(ens) bind(C, name="xee_ensemble_ee_scalars") result(st)
+        import :: c_int, c_ptr
+        type(c_ptr), value :: ens
+        integer(c_int) :: st
+    end function
+
+    function xee_ensemble_records(ens, rec) bind(C, name="xee_ensemble_records") result(st)
+        import :: c_int, c_ptr, xee_case_record
+        type(c_ptr), value :: ens
+        type(xee_case_record), intent(out) :: rec(*)
+        integer(c_int) :: st
+    end function
+end interface
+
+contains
+
+! abort with libxee's message; there is no CPU fallback to fall back to
+subroutine xee_check(st, where)
+implicit none
+integer(c_int), intent(in) :: st
+character(*), intent(in) :: where
+character(kind=c_char), pointer :: msg(:)
+type(c_ptr) :: p
+integer :: n
+
+if (st == XEE_OK) return
+p = xee_last_error()
+n = 0
+if (c_associated(p)) then
+    call c_f_pointer(p, msg, [512])
+    do while (n < 512)
+        if (msg(n+1) == c_null_char) exit
+        n = n + 1
+    end do
+    write (*, '(A,A,A,I0,A,512A1)') "ERROR: libxee ", where, " failed with status ", st, ": ", msg(1:n)
+else
+    write (*, '(A,A,A,I0)') "ERROR: libxee ", where, " failed with status ", st
+end if
+error stop 1
+end subroutine
+
+end module xee_c_api
