@@ -76,6 +76,12 @@ int xee_solve_elliptic(int *max_iter, int check_step, int converge_time, int los
                        float *dat, const float *coe, const float *f, float *workspace,
                        int nx, int ny, int *err, int debug);
 
+/* replaces the residual norm inside solve_elliptic, elliptic_tools.f90:193-199, as a stand-alone call:
+ * *sum_sq = the sequential fp32 sum (i outer, j inner) of res(i,j)**2 over the interior, bit for bit;
+ * *rms = sqrt(sum_sq / ((nx-2)*(ny-2))).  slow_chunks (may be NULL) reports how many 32-term chunks the
+ * parallel algorithm had to add term by term (xee_exactsum.hip). */
+int xee_residual_norm(const float *res, int nx, int ny, float *sum_sq, float *rms, int *slow_chunks);
+
 /* replaces judge_error, elliptic_tools.f90:333-358 (prints the same texts to stdout). */
 void xee_judge_error(int err);
 

@@ -166,7 +166,7 @@ void orc_do_elliptic(const float *psi, const float *coe, float *outdat, int nx, 
 
 /* xtt-lib-fortran/elliptic_tools.f90:193-199: err_now = sqrt(sum/((nx-2)*(ny-2))), sequential
  * fp32, I outer / J inner, to_dat**2.0 == x*x. */
-float orc_residual_rms(const float *res, int nx, int ny)
+float orc_residual_sumsq(const float *res, int nx, int ny)
 {
     float s = 0.0f;
     for (int i = 1; i <= nx - 2; ++i)
@@ -174,7 +174,12 @@ float orc_residual_rms(const float *res, int nx, int ny)
             float x = res[IDX(i, j, nx)];
             s = s + x * x;
         }
-    return sqrtf(s / (float)((nx - 2) * (ny - 2)));
+    return s;
+}
+
+float orc_residual_rms(const float *res, int nx, int ny)
+{
+    return sqrtf(orc_residual_sumsq(res, nx, ny) / (float)((nx - 2) * (ny - 2)));
 }
 
 /* xtt-lib-fortran/elliptic_tools.f90:333-358 */

@@ -80,6 +80,7 @@ int orc_solve_elliptic_reforder(int *max_iter, int check_step, int converge_time
 /* A4 alone: sequential fp32 RMS of the interior of a residual plane, i outer / j inner
  * (elliptic_tools.f90:193-199). */
 float orc_residual_rms(const float *res, int nx, int ny);
+float orc_residual_sumsq(const float *res, int nx, int ny);   /* the raw sequential sum of squares */
 
 /* finite differences, src/diagnose/quick-tools2.f90 (and the identical copies in
  * src/old-diagnose/diagnose.f90:943-1027).  Untouched output entries stay untouched. */

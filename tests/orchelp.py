@@ -56,6 +56,8 @@ def oracle():
         fn.restype = i32
     L.orc_residual_rms.argtypes = [f32p, i32, i32]
     L.orc_residual_rms.restype = f32
+    L.orc_residual_sumsq.argtypes = [f32p, i32, i32]
+    L.orc_residual_sumsq.restype = f32
     for fn in (L.orc_d_dz_B2A, L.orc_d_dz_O2C, L.orc_d_dr_B2B, L.orc_d_dr_B2C, L.orc_d_dr_O2A):
         fn.argtypes = [f32p, f32p, f32p, i32, i32]
     L.orc_d_rcuvdr_O2A.argtypes = [f32p, f32p, f32p, f32p, i32, i32]

@@ -243,3 +243,59 @@ def test_single_step_flag_equals_blocked_path():
     b = xee.diagnose_case(A, B, Cc, bc, flags=1, **cfg)["BAROTROPIC"]      # XEE_SOLVE_SINGLE_STEP
     assert biteq(a["psi"], b["psi"]) and a["r1"].tobytes() == b["r1"].tobytes()
     assert a["timing"]["sweep_launches"] < b["timing"]["sweep_launches"] == 333
+
+
+# ---- parallel order-exact residual norm (xee_exactsum.hip) --------------------------------------
+
+def _planes():
+    rng = np.random.default_rng(1234)
+    out = {}
+    out["normal_37x29"] = rng.standard_normal((29, 37)).astype(np.float32)
+    out["normal_200x200"] = (1e-3 * rng.standard_normal((200, 200))).astype(np.float32)
+    out["normal_1024x512"] = (1e-4 * rng.standard_normal((512, 1024))).astype(np.float32)
+    out["tall_130x2100"] = rng.standard_normal((2100, 130)).astype(np.float32)          # > 64 chunks per column
+    out["zeros"] = np.zeros((64, 96), np.float32)
+    one = np.zeros((64, 96), np.float32); one[40, 50] = 3.0
+    out["single"] = one
+    # squares that are exact small multiples of powers of two: round-to-even ties everywhere
+    out["ties"] = (2.0 ** rng.integers(-6, 3, size=(150, 260)) * rng.integers(0, 4, size=(150, 260))).astype(np.float32)
+    out["wide_range"] = (10.0 ** rng.uniform(-12, 6, size=(120, 300)) * rng.choice([-1, 1], size=(120, 300))).astype(np.float32)
+    out["tiny"] = (1e-23 * rng.standard_normal((90, 70))).astype(np.float32)             # squares are subnormal / underflow
+    grow = np.zeros((40, 50), np.float32)
+    grow[1:-1, 1:-1] = (1.7 ** np.arange(48 * 38)).reshape(48, 38).T.clip(max=1e18)       # each term dwarfs the sum so far
+    out["growing"] = grow
+    shr = np.zeros((40, 50), np.float32)
+    shr[1:-1, 1:-1] = (0.9 ** np.arange(48 * 38)).reshape(48, 38).T                       # terms vanish below half an ulp
+    out["shrinking"] = shr
+    big = rng.standard_normal((64, 64)).astype(np.float32); big[20, 20] = 1e19; big[21, 20] = 3e19   # overflow to +inf
+    out["overflow"] = big
+    nan = rng.standard_normal((64, 64)).astype(np.float32); nan[10, 33] = np.nan
+    out["nan"] = nan
+    return out
+
+
+@pytest.mark.parametrize("name", list(_planes().keys()))
+def test_exact_residual_norm_adversarial(name):
+    res = _planes()[name]
+    ny, nx = res.shape
+    with np.errstate(all="ignore"):
+        want = np.float32(H.oracle().orc_residual_sumsq(res, nx, ny))
+        want_rms = np.float32(H.oracle().orc_residual_rms(res, nx, ny))
+    got, rms, slow = xee.residual_norm(res)
+    assert got.tobytes() == want.tobytes() or (np.isnan(got) and np.isnan(want)), (name, got, want, slow)
+    assert rms.tobytes() == want_rms.tobytes() or (np.isnan(rms) and np.isnan(want_rms))
+    nchunks = (nx - 2) * -(-(ny - 2) // 32)
+    if name.startswith("normal") or name == "tall_130x2100":
+        assert slow < 0.02 * nchunks + 40, (slow, nchunks)      # the fast path must actually be taken
+
+
+def test_exact_norm_equals_serial_walk_in_solver(monkeypatch):
+    """Same solve with the single-lane reference-order walk and with the parallel algorithm."""
+    A, B, Cc, bc = H.rich_inputs(64, 48, seed=13)
+    cfg = dict(r1=1e-6, r2=2e-3, max_iter=100000, alpha=1.0, domain=(0.0, 2.0e5, 0.0, 1.5e4))
+    a = xee.diagnose_case(A, B, Cc, bc, **cfg)["BAROTROPIC"]
+    monkeypatch.setenv("XEE_EXACT_SUM", "serial")
+    b = xee.diagnose_case(A, B, Cc, bc, **cfg)["BAROTROPIC"]
+    assert int(a["iters"][0]) == int(b["iters"][0]) and biteq(a["psi"], b["psi"])
+    assert a["r1"].tobytes() == b["r1"].tobytes() and a["r2"].tobytes() == b["r2"].tobytes()
+    assert int(a["err"][0]) == 0, "this case is meant to converge before max_iter"

@@ -35,6 +35,19 @@ struct MemberState {
     float ratio;       // strategy_r2 on return
 };
 
+// what a run of terms adds to a running fp32 sum that stays inside one binade (xee_exactsum.hip)
+struct ExactSum {
+    unsigned ke, ko;   // ulps added when the incoming ulp count is even / odd
+    int eu;            // log2(ulp) of the binade the counts are valid for
+    int valid;
+};
+constexpr int EXACT_SEG = 32;   // terms per chunk
+size_t exact_ws_bytes(const Grid& g);
+// out_sums[m] = the reference's sequential fp32 sum of R(i,j)^2 over the interior, bit for bit
+void launch_exact_sumsq(const Grid& g, const float* R, void* workspace, float* out_sums,
+                        int* slow_chunks /* optional: chunks summed term by term */,
+                        const MemberState* st, hipStream_t s);
+
 struct ConvParams {
     float r1, r2;          // after the <=0 -> HUGE substitution (:112-124)
     int converge_time;     // :136-139

@@ -72,6 +72,7 @@ def lib():
     L.xee_do_elliptic.argtypes = [_f32p, _f32p, _f32p, C.c_int, C.c_int, _pi]
     L.xee_solve_elliptic.argtypes = [_pi, C.c_int, C.c_int, C.c_int, _pf, _pf, C.c_float, _f32p, _f32p, _f32p, _f32p,
                                      C.c_int, C.c_int, _pi, C.c_int]
+    L.xee_residual_norm.argtypes = [_f32p, C.c_int, C.c_int, _pf, _pf, _pi]
     L.xee_judge_error.argtypes = [C.c_int]
     L.xee_judge_error.restype = None
     L.xee_solver_coefficients.argtypes = [_f32p] * 8 + [C.c_int, C.c_int]
@@ -160,6 +161,14 @@ def solve_elliptic(dat, coe, f, max_iter, r1, r2, alpha, check_step=100, converg
     _chk(lib().xee_solve_elliptic(C.byref(mi), check_step, converge_time, lost_rate, C.byref(a), C.byref(b),
                                   float(alpha), psi, _a(coe), _a(f), wk, nx, ny, C.byref(e), debug))
     return psi, mi.value, e.value, np.float32(a.value), np.float32(b.value)
+
+
+def residual_norm(res):
+    """elliptic_tools.f90:193-199 -> (sum_sq, rms, slow_chunks), order-exact."""
+    ny, nx = res.shape
+    s, r, slow = C.c_float(), C.c_float(), C.c_int()
+    _chk(lib().xee_residual_norm(_a(res), nx, ny, C.byref(s), C.byref(r), C.byref(slow)))
+    return np.float32(s.value), np.float32(r.value), slow.value
 
 
 def solver_coefficients(A, B, Cc, rcuva, rho):
