@@ -299,3 +299,32 @@ def test_exact_norm_equals_serial_walk_in_solver(monkeypatch):
     assert int(a["iters"][0]) == int(b["iters"][0]) and biteq(a["psi"], b["psi"])
     assert a["r1"].tobytes() == b["r1"].tobytes() and a["r2"].tobytes() == b["r2"].tobytes()
     assert int(a["err"][0]) == 0, "this case is meant to converge before max_iter"
+
+
+# ---- uniform coefficient planes are elided from the blocked kernel ------------------------------
+
+def test_uniform_plane_elision_nonzero_constants():
+    """Corner coefficient planes that are uniform (any value, here non-zero) are kept in scalars by the
+    blocked kernel instead of being loaded: same bits as the oracle fed the full 9-plane array."""
+    nr, nz = 150, 90
+    rng = np.random.default_rng(3)
+    coe = np.zeros((nz, nr, 9), np.float32)
+    coe[..., 4] = -(4.0 + rng.random((nz, nr))).astype(np.float32)
+    for k in (1, 3, 5, 7):
+        coe[..., k] = (1.0 + 0.1 * rng.random((nz, nr))).astype(np.float32)
+    for k, v in ((0, 0.015625), (2, -0.03125), (6, 0.0078125), (8, -0.0)):
+        coe[..., k] = np.float32(v)
+    f = (1e-2 * rng.standard_normal((nz, nr))).astype(np.float32)
+    bc = (1e-3 * rng.standard_normal((nz, nr))).astype(np.float32)
+    want = H.solve(bc, coe, f, 237, 1e-8, -1.0, 0.9)
+    got = xee.solve_elliptic(bc, coe, f, 237, 1e-8, -1.0, 0.9)
+    assert biteq(got[0], want[0]) and got[3].tobytes() == want[3].tobytes()
+
+
+def test_elision_on_off_same_bits(monkeypatch):
+    A, B, Cc, bc = H.test1_inputs(200, 200)
+    cfg = dict(r1=1e-8, r2=-1.0, max_iter=400, alpha=1.0)
+    a = xee.diagnose_case(A, B, Cc, bc, **cfg)["BAROTROPIC"]
+    monkeypatch.setenv("XEE_NO_ELISION", "1")
+    b = xee.diagnose_case(A, B, Cc, bc, **cfg)["BAROTROPIC"]
+    assert biteq(a["psi"], b["psi"]) and a["r1"].tobytes() == b["r1"].tobytes()

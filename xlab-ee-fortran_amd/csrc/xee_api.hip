@@ -74,10 +74,12 @@ struct xee_ensemble {
     std::vector<xee_case_record_t> rec;
     xee_timing_t timing{};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    int tb_T = 8;   // iterations per temporally blocked launch (XEE_TB_T overrides)
+    int tb_T = 6;   // iterations per temporally blocked launch (XEE_TB_T overrides)
     void* ex_ws = nullptr;       // workspace of the parallel order-exact residual norm
     int* ex_slow = nullptr;      // per member: chunks the last check summed term by term
     bool exact_serial = false;   // XEE_EXACT_SUM=serial: single-lane reference-order walk instead
+    UniformVals uv{};            // coefficient planes found uniform by the last assemble / coe upload
+    unsigned* uv_differs = nullptr;
 };
 
 namespace {
@@ -132,6 +134,26 @@ int field_ref(xee_ensemble* e, int field, float** base, int* n1, int* n2)
     }
     XCHK(alloc_planes(e, p));
     *base = *p;
+    return XEE_OK;
+}
+
+int check_launch(const char* what);
+
+// after the coefficient planes changed: find the ones that are uniform over the whole batch
+int detect_uniform_planes(xee_ensemble* e)
+{
+    e->uv = UniformVals{};
+    if (!e->uv_differs) HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->uv_differs), sizeof(unsigned)));
+    launch_uniform_check(e->g, e->coe, e->uv_differs, e->stream);
+    unsigned differs = 0x1ffu;
+    HIPCHK(hipMemcpyAsync(&differs, e->uv_differs, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
+    float v[9];
+    const size_t ks = (size_t)e->g.members * e->g.plane;
+    for (int k = 0; k < 9; ++k)
+        HIPCHK(hipMemcpyAsync(&v[k], e->coe + k * ks + e->g.pitch + 1, sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->uv.mask = (~differs) & 0x1ffu;
+    for (int k = 0; k < 9; ++k) e->uv.v[k] = v[k];
     return XEE_OK;
 }
 
@@ -282,6 +304,7 @@ int xee_ensemble_destroy(xee_ensemble_t* e)
     if (e->st) hipFree(e->st);
     if (e->ex_ws) hipFree(e->ex_ws);
     if (e->ex_slow) hipFree(e->ex_slow);
+    if (e->uv_differs) hipFree(e->uv_differs);
     if (e->st_host) hipHostFree(e->st_host);
     if (e->sums_host) hipHostFree(e->sums_host);
     for (auto& ev : e->ev) if (ev) hipEventDestroy(ev);
@@ -338,6 +361,7 @@ static int xfer(xee_ensemble_t* e, int field, int first, int count, float* host,
     float* base = nullptr;
     int n1 = 0, n2 = 0;
     XCHK(field_ref(e, field, &base, &n1, &n2));
+    if (up && field >= XEE_F_COE0) e->uv.mask = 0;   // planes changed behind assemble's back: assume nothing
     for (int k = 0; k < count; ++k) {
         float* d = base + (size_t)(first + k) * e->g.plane;
         float* h = host + (size_t)k * n1 * n2;
@@ -395,7 +419,8 @@ int xee_ensemble_assemble(xee_ensemble_t* e, int variant)
     XCHK(alloc_planes(e, &e->sC));
     launch_solver_coef(e->g, e->A, e->B, e->C, e->rcuva, e->rho, e->sA, e->sB, e->sC, e->stream);
     launch_cal_coe(e->g, e->sA, variant == XEE_BAROCLINIC ? e->sB : nullptr, e->sC, e->coe, e->dr, e->dz, e->stream);
-    return check_launch("assemble");
+    XCHK(check_launch("assemble"));
+    return detect_uniform_planes(e);
 }
 
 // solve_elliptic, xtt-lib-fortran/elliptic_tools.f90:93-265, for every member at once.
@@ -445,7 +470,7 @@ int xee_ensemble_solve(xee_ensemble_t* e, int max_iter, int check_step, int conv
         if (n == 1)
             launch_sweep(g, e->psi[cur], e->psi[cur ^ 1], e->coe, e->f, check ? e->res : nullptr, e->st, alpha, s);
         else
-            launch_sweep_tb(g, e->psi[cur], e->psi[cur ^ 1], e->coe, e->f, check ? e->res : nullptr, e->st, alpha, n, s);
+            launch_sweep_tb(g, e->psi[cur], e->psi[cur ^ 1], e->coe, e->f, check ? e->res : nullptr, e->st, alpha, n, e->uv, s);
         cur ^= 1;
         e->timing.sweep_launches += 1;
         e->timing.iterations += n;
@@ -580,7 +605,7 @@ int xee_ensemble_time_sweeps(xee_ensemble_t* e, int iters, int variant, float al
     for (int k = 0; k < iters;) {
         const int n = variant == 0 ? 1 : ((iters - k) < e->tb_T ? (iters - k) : e->tb_T);
         if (n == 1) launch_sweep(g, e->psi[cur], e->psi[cur ^ 1], e->coe, e->f, nullptr, e->st, alpha, s);
-        else launch_sweep_tb(g, e->psi[cur], e->psi[cur ^ 1], e->coe, e->f, nullptr, e->st, alpha, n, s);
+        else launch_sweep_tb(g, e->psi[cur], e->psi[cur ^ 1], e->coe, e->f, nullptr, e->st, alpha, n, e->uv, s);
         cur ^= 1;
         k += n;
         ++nl;
@@ -642,7 +667,7 @@ static int upload_coe_aos(xee_ensemble_t* e, const float* coe)
     if (he == hipSuccess) he = hipGetLastError();
     hipFree(aos);
     if (he != hipSuccess) return fail(XEE_ERR_HIP, std::string("coe upload: ") + hipGetErrorString(he));
-    return XEE_OK;
+    return detect_uniform_planes(e);
 }
 
 int xee_do_elliptic(const float* psi, const float* coe, float* outdat, int nx, int ny, int* err)

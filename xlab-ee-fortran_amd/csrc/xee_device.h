@@ -69,10 +69,16 @@ void launch_apply(const Grid& g, const float* psi, const float* coe, float* out,
 void launch_sweep(const Grid& g, const float* psi_in, float* psi_out, const float* coe,
                   const float* f, float* res /* nullptr: not written */, const MemberState* st,
                   float alpha, hipStream_t s);
+// coefficient planes that hold one bit pattern over the interior of every member (set by assemble)
+struct UniformVals {
+    unsigned mask;   // bit k: plane k is uniform
+    float v[9];      // its value
+};
+void launch_uniform_check(const Grid& g, const float* coe, unsigned* differs /* device, 1 word */, hipStream_t s);
 // T damped-Jacobi iterations in one launch (temporally blocked kernel), 2 <= T <= tb_max_T()
 void launch_sweep_tb(const Grid& g, const float* psi_in, float* psi_out, const float* coe,
                      const float* f, float* res /* residual of the LAST iteration, or nullptr */,
-                     const MemberState* st, float alpha, int T, hipStream_t s);
+                     const MemberState* st, float alpha, int T, const UniformVals& uv, hipStream_t s);
 int  tb_max_T();
 // sequential fp32 sum, reference loop order (i outer, j inner), of T or T*T over a sub-rectangle
 void launch_seqsum(const Grid& g, const float* T, int i0, int i1, int j0, int j1, bool square,

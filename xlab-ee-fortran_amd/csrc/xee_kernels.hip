@@ -9,6 +9,10 @@
 // 256-byte-per-wave (dword) or 1-KiB-per-wave (dwordx4) row segment.
 #include "xee_device.h"
 
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
 #pragma clang fp contract(off)
 
 namespace xee {
@@ -216,10 +220,15 @@ __global__ __launch_bounds__(256) void k_sweep_stream(Grid g, const float* __res
 //     only the region whose dependency cone stayed inside the tile (or hit the Dirichlet rim) is
 //     stored.  HBM bytes per useful point-iteration ~ 48 / (T * tile efficiency).
 // =============================================================================================
-template <int NW, int R, bool WRITE_R>
+//     UMASK: compile-time set of coefficient planes that are UNIFORM over the whole batch (detected
+//     at assemble time, e.g. the four corner coefficients of the BAROTROPIC operator are all -0/+0):
+//     they are not loaded and cost no registers -- same value, same multiply, same bits.
+#define TB_C(k) ((((UMASK) >> (k)) & 1u) ? uv.v[k] : c[k][r])
+
+template <int NW, int R, bool WRITE_R, unsigned UMASK>
 __global__ __launch_bounds__(NW * 64) void k_sweep_tb(Grid g, const float* __restrict__ psi_in,
         float* __restrict__ psi_out, const float* __restrict__ coe, const float* __restrict__ f,
-        float* __restrict__ res, const MemberState* __restrict__ st, float alpha, int T)
+        float* __restrict__ res, const MemberState* __restrict__ st, float alpha, int T, UniformVals uv)
 {
     __shared__ float edge[2][2][NW][64];
     const int m = blockIdx.z;
@@ -236,7 +245,7 @@ __global__ __launch_bounds__(NW * 64) void k_sweep_tb(Grid g, const float* __res
     const size_t mo = (size_t)m * g.plane;
     const size_t ks = (size_t)g.members * g.plane;
 
-    float c[9][R], ff[R], p[R];
+    float c[9][R], ff[R], p[R];                           // rows of uniform planes are never touched -> no registers
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int gy = gy0 + r;
@@ -246,7 +255,8 @@ __global__ __launch_bounds__(NW * 64) void k_sweep_tb(Grid g, const float* __res
         p[r] = in ? psi_in[o] : 0.0f;
         ff[r] = interior ? f[o] : 0.0f;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) c[k][r] = interior ? coe[k * ks + o] : 0.0f;
+        for (int k = 0; k < 9; ++k)
+            if (!((UMASK >> k) & 1u)) c[k][r] = interior ? coe[k * ks + o] : 0.0f;
     }
 
     // validity after T iterations: dependency cone inside the tile, or cut by the domain edge (rim
@@ -265,17 +275,17 @@ __global__ __launch_bounds__(NW * 64) void k_sweep_tb(Grid g, const float* __res
         for (int r = 0; r < R; ++r) {
             const float on = (r + 1 < R) ? p[r + 1] : above;
             const float onl = wave_shr1(0.0f, on), onr = wave_shl1(0.0f, on);
-            float Rv = c[0][r] * onl;                     // elliptic_tools.f90:77-85, left to right
-            Rv = Rv + c[1][r] * on;
-            Rv = Rv + c[2][r] * onr;
-            Rv = Rv + c[3][r] * ocl;
-            Rv = Rv + c[4][r] * oc;
-            Rv = Rv + c[5][r] * ocr;
-            Rv = Rv + c[6][r] * oml;
-            Rv = Rv + c[7][r] * om;
-            Rv = Rv + c[8][r] * omr;
+            float Rv = TB_C(0) * onl;                     // elliptic_tools.f90:77-85, left to right
+            Rv = Rv + TB_C(1) * on;
+            Rv = Rv + TB_C(2) * onr;
+            Rv = Rv + TB_C(3) * ocl;
+            Rv = Rv + TB_C(4) * oc;
+            Rv = Rv + TB_C(5) * ocr;
+            Rv = Rv + TB_C(6) * oml;
+            Rv = Rv + TB_C(7) * om;
+            Rv = Rv + TB_C(8) * omr;
             Rv = Rv - ff[r];                              // :190
-            const float upd = oc + alpha * Rv / (-c[4][r]);   // :238
+            const float upd = oc + alpha * Rv / (-TB_C(4));   // :238
             const int gy = gy0 + r;
             const bool interior = col_int && gy >= 1 && gy <= g.ny - 2;
             p[r] = interior ? upd : oc;
@@ -658,24 +668,71 @@ void launch_sweep(const Grid& g, const float* psi_in, float* psi_out, const floa
     else launch_sweep_rj<1>(g, psi_in, psi_out, coe, f, res, st, alpha, s);
 }
 
-template <int NW, int R>
+template <int NW, int R, unsigned UMASK>
 static void launch_tb_cfg(const Grid& g, const float* psi_in, float* psi_out, const float* coe, const float* f,
-                          float* res, const MemberState* st, float alpha, int T, hipStream_t s)
+                          float* res, const MemberState* st, float alpha, int T, const UniformVals& uv, hipStream_t s)
 {
     constexpr int H = NW * R;
     dim3 grid((g.nx - 1 + (64 - 2 * T) - 1) / (64 - 2 * T), (g.ny - 1 + (H - 2 * T) - 1) / (H - 2 * T), g.members);
     if (res)
-        hipLaunchKernelGGL((k_sweep_tb<NW, R, true>), grid, dim3(NW * 64), 0, s, g, psi_in, psi_out, coe, f, res, st, alpha, T);
+        hipLaunchKernelGGL((k_sweep_tb<NW, R, true, UMASK>), grid, dim3(NW * 64), 0, s, g, psi_in, psi_out, coe, f, res, st, alpha, T, uv);
     else
-        hipLaunchKernelGGL((k_sweep_tb<NW, R, false>), grid, dim3(NW * 64), 0, s, g, psi_in, psi_out, coe, f, res, st, alpha, T);
+        hipLaunchKernelGGL((k_sweep_tb<NW, R, false, UMASK>), grid, dim3(NW * 64), 0, s, g, psi_in, psi_out, coe, f, res, st, alpha, T, uv);
 }
 
 int tb_max_T() { return 16; }
 
 void launch_sweep_tb(const Grid& g, const float* psi_in, float* psi_out, const float* coe, const float* f,
-                     float* res, const MemberState* st, float alpha, int T, hipStream_t s)
+                     float* res, const MemberState* st, float alpha, int T, const UniformVals& uv, hipStream_t s)
 {
-    launch_tb_cfg<8, 16>(g, psi_in, psi_out, coe, f, res, st, alpha, T, s);
+    // tile shape: NW waves x R rows (x 64 columns).  XEE_TB_CFG=<NW>x<R> overrides for experiments.
+    static const int cfg = [] {
+        const char* e = getenv("XEE_TB_CFG");
+        int nw = 0, r = 0;
+        if (e && sscanf(e, "%dx%d", &nw, &r) == 2) return nw * 100 + r;
+        return 0;
+    }();
+    constexpr unsigned BARO = 0x145u;     // planes 1,3,7,9 of the reference's numbering (corner coefficients)
+    const bool baro = (uv.mask & BARO) == BARO && !getenv("XEE_NO_ELISION");
+#define TB_CASE(NW, R) case NW * 100 + R: \
+        if (baro) launch_tb_cfg<NW, R, BARO>(g, psi_in, psi_out, coe, f, res, st, alpha, T, uv, s); \
+        else launch_tb_cfg<NW, R, 0u>(g, psi_in, psi_out, coe, f, res, st, alpha, T, uv, s); \
+        break;
+    switch (cfg) {
+        TB_CASE(8, 16)
+        TB_CASE(8, 12)
+        TB_CASE(8, 8)
+        TB_CASE(4, 12)
+        TB_CASE(4, 8)
+        TB_CASE(2, 16)
+        TB_CASE(16, 8)
+        default:   // measured best on MI355X (profiles/r01): 2 workgroups per CU so loads overlap compute
+            if (baro) launch_tb_cfg<8, 8, BARO>(g, psi_in, psi_out, coe, f, res, st, alpha, T, uv, s);
+            else launch_tb_cfg<4, 16, 0u>(g, psi_in, psi_out, coe, f, res, st, alpha, T, uv, s);
+    }
+#undef TB_CASE
+}
+
+// which coefficient planes hold one and the same bit pattern over the interior of EVERY member
+__global__ __launch_bounds__(256) void k_uniform_check(Grid g, const float* __restrict__ coe, unsigned* __restrict__ differs)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int j = blockIdx.y * 4 + threadIdx.y;
+    if (i < 1 || i > g.nx - 2 || j < 1 || j > g.ny - 2) return;
+    const size_t o = (size_t)blockIdx.z * g.plane + (size_t)j * g.pitch + i;
+    const size_t ref = (size_t)g.pitch + 1;               // member 0, point (1,1)
+    const size_t ks = (size_t)g.members * g.plane;
+    unsigned bad = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+        if (__builtin_bit_cast(unsigned, coe[k * ks + o]) != __builtin_bit_cast(unsigned, coe[k * ks + ref])) bad |= 1u << k;
+    if (bad) atomicOr(differs, bad);
+}
+
+void launch_uniform_check(const Grid& g, const float* coe, unsigned* differs, hipStream_t s)
+{
+    hipMemsetAsync(differs, 0, sizeof(unsigned), s);
+    hipLaunchKernelGGL(k_uniform_check, grid2d(g), kBlk, 0, s, g, coe, differs);
 }
 
 static void seqsum_shape(const Grid& g, int nrows, int* TC, int* colstride)
