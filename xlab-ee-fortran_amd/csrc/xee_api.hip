@@ -251,6 +251,7 @@ int xee_ensemble_create(xee_ensemble_t** out, int nr, int nz, int n_members, int
     HIPCHK(hipSetDevice(device));
     if (!g_setup_done) {
         int s = sweep_kernel_setup();
+        if (s == 0) s = exact_kernel_setup();
         if (s != 0) return fail(XEE_ERR_HIP, std::string("kernel setup: ") + hipGetErrorString((hipError_t)s));
         g_setup_done = true;
     }

@@ -43,6 +43,7 @@ struct ExactSum {
 };
 constexpr int EXACT_SEG = 32;   // terms per chunk
 size_t exact_ws_bytes(const Grid& g);
+int    exact_kernel_setup();    // one-time function attributes; returns hipError_t as int
 // out_sums[m] = the reference's sequential fp32 sum of R(i,j)^2 over the interior, bit for bit
 void launch_exact_sumsq(const Grid& g, const float* R, void* workspace, float* out_sums,
                         int* slow_chunks /* optional: chunks summed term by term */,

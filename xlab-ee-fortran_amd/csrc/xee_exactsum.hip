@@ -12,17 +12,20 @@
 //   an integer number of ulps, round-to-nearest with ties decided by the parity of S.  The number of
 //   ulps a run of terms adds therefore depends on the incoming sum only through (a) the binade and
 //   (b) the parity of S.  So:
-//     A. per chunk of 32 consecutive terms (in reference order): fp64 sum            (parallel)
-//     B. exclusive scan of the chunk sums -> predicted running sum, hence predicted binade, at
-//        every chunk start                                                            (parallel)
+//     A. per chunk of 32 consecutive terms (in reference order): fp64 sum              (parallel)
+//     B. exclusive scan of the chunk sums (per column, then over the column totals) -> predicted
+//        running sum, hence predicted binade, at every chunk start                      (parallel)
 //     C. per chunk, for its predicted binade: the ulp counts K_even / K_odd it adds for an even /
-//        odd incoming S (exact integer arithmetic on the fp32 fields; ties handled) (parallel)
-//     D. per column: compose its chunks' (K_even, K_odd) when they share one binade  (parallel)
-//     E. one wave per member walks the columns in reference order: bits += K[parity] whenever the
-//        actual binade equals the predicted one and the sum stays inside it -- checked on the real
-//        bit pattern, so a wrong prediction can only cost time -- else it descends to the column's
-//        chunks, and for a chunk that still does not fit (binade crossing, a term larger than half
-//        the sum, NaN/Inf) performs the 32 genuine fp32 additions.
+//        odd incoming S (exact integer arithmetic on the fp32 fields; ties handled)   (parallel)
+//     D. per column: compose its chunks' (K_even, K_odd) when they share one binade    (parallel)
+//     E. one wave per member walks the columns in reference order.  Composition of the (K_even,
+//        K_odd) maps is associative, so an inclusive WAVE SCAN over the next 64 summaries gives all
+//        64 run lengths at once; the longest run that is valid for the ACTUAL binade and keeps the
+//        sum inside it is applied with one integer add on the bit pattern.  Everything is checked
+//        on the real bits, so a wrong prediction can only cost time.  A column that does not fit
+//        is walked over its chunks the same way (their summaries were staged in LDS up front for
+//        the columns known to be composite-invalid); a chunk that still does not fit -- binade
+//        crossing, a term above half the sum, NaN/Inf -- gets its 32 genuine fp32 additions.
 //   Typically ~25 of the 16,352 chunks of a 1024x512 plane take the slow path.
 #include "xee_device.h"
 
@@ -33,6 +36,7 @@ namespace xee {
 namespace {
 
 constexpr int SEG = EXACT_SEG;
+constexpr int MAXREP = 48;      // columns whose chunk summaries are staged in LDS for the walk
 
 __device__ __forceinline__ unsigned f2u(float x) { return __builtin_bit_cast(unsigned, x); }
 __device__ __forceinline__ float u2f(unsigned x) { return __builtin_bit_cast(float, x); }
@@ -44,10 +48,10 @@ __device__ __forceinline__ int ulp_exp(unsigned bits)
     return (E > 0 ? E : 1) - 150;
 }
 
-// chunk c = (column, segment) of member m: terms R(i, j0 + seg*SEG + r)^2, r = 0..SEG-1
+// chunk (column, segment) of one member: terms R(1+col, 1 + seg*SEG + r)^2, r = 0..n-1
 struct ChunkAddr {
-    const float* p;   // first term's x
-    int n;            // number of terms in this chunk
+    const float* p;
+    int n;
 };
 
 __device__ __forceinline__ ChunkAddr chunk_addr(const Grid& g, const float* Rm, int col, int seg, int nrows)
@@ -55,8 +59,54 @@ __device__ __forceinline__ ChunkAddr chunk_addr(const Grid& g, const float* Rm, 
     ChunkAddr a;
     const int r0 = seg * SEG;
     a.n = min(SEG, nrows - r0);
-    a.p = Rm + (size_t)(1 + r0) * g.pitch + (1 + col);     // interior starts at (1,1)
+    a.p = Rm + (size_t)(1 + r0) * g.pitch + (1 + col);
     return a;
+}
+
+// exact ulp counts a chunk adds to a sum whose ulp is 2^eu (valid while the sum stays in that binade)
+__device__ __forceinline__ ExactSum chunk_summary(const ChunkAddr& a, int pitch, int eu)
+{
+    unsigned ke = 0, ko = 0;
+    bool ok = true;
+    for (int r = 0; r < a.n; ++r) {
+        const float x = a.p[(size_t)r * pitch];
+        const unsigned tb = f2u(x * x);                      // to_dat(i,j)**2.0, >= +0
+        const unsigned Et = (tb >> 23) & 0xffu;
+        const unsigned fr = tb & 0x7fffffu;
+        if (Et == 255u) { ok = false; break; }               // Inf / NaN term: genuine adds only
+        const unsigned Mt = Et ? (fr | 0x800000u) : fr;
+        if (Mt == 0u) continue;                              // + 0
+        const int shift = eu - ((int)(Et ? Et : 1u) - 150);
+        if (shift <= 0) { ok = false; break; }               // term >= 2^23 ulps: leaves the binade
+        if (shift >= 25) continue;                           // < half an ulp: absorbed
+        const unsigned q = Mt >> shift;
+        const unsigned rem = Mt & ((1u << shift) - 1u);
+        const unsigned half = 1u << (shift - 1);
+        const unsigned up_e = (rem > half) || (rem == half && ((ke + q) & 1u));
+        const unsigned up_o = (rem > half) || (rem == half && (((ko + q) & 1u) ^ 1u));
+        ke += q + up_e;
+        ko += q + up_o;
+    }
+    ExactSum out;
+    out.eu = eu;
+    out.valid = (ok && ke < (1u << 24) && ko < (1u << 24)) ? 1 : 0;
+    out.ke = out.valid ? ke : 0u;
+    out.ko = out.valid ? ko : 0u;
+    return out;
+}
+
+// run `a` followed by run `b`
+__device__ __forceinline__ ExactSum compose(const ExactSum& a, const ExactSum& b)
+{
+    const unsigned ke = a.ke + ((a.ke & 1u) ? b.ko : b.ke);                 // parity after a, incoming even
+    const unsigned ko = a.ko + (((a.ko & 1u) ^ 1u) ? b.ko : b.ke);          // parity after a, incoming odd
+    const bool ok = a.valid && b.valid && a.eu == b.eu && ke < (1u << 24) && ko < (1u << 24);
+    ExactSum o;
+    o.eu = a.eu;
+    o.valid = ok ? 1 : 0;
+    o.ke = ok ? ke : 0u;
+    o.ko = ok ? ko : 0u;
+    return o;
 }
 
 }  // namespace
@@ -80,19 +130,33 @@ __global__ __launch_bounds__(256) void k_ex_chunk_sums(Grid g, const float* __re
     sigma[(size_t)m * ncol * nseg + (size_t)col * nseg + seg] = acc;
 }
 
-// B. exclusive scan over the chunks of one member, reference order (column-major over chunks)
-__global__ __launch_bounds__(1024) void k_ex_scan(int nchunk, const double* __restrict__ sigma,
-        double* __restrict__ prefix, const MemberState* __restrict__ st)
+// B1. per column: exclusive prefix of its chunk sums (in place) and the column total
+__global__ __launch_bounds__(256) void k_ex_col_prefix(int ncol, int nseg, double* __restrict__ sigma,
+        double* __restrict__ coltot, const MemberState* __restrict__ st)
+{
+    const int m = blockIdx.y;
+    if (st && !st[m].active) return;
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= ncol) return;
+    double* sg = sigma + ((size_t)m * ncol + col) * nseg;
+    double run = 0.0;
+    for (int k = 0; k < nseg; ++k) { const double v = sg[k]; sg[k] = run; run += v; }
+    coltot[(size_t)m * ncol + col] = run;
+}
+
+// B2. exclusive scan of the column totals of one member
+__global__ __launch_bounds__(1024) void k_ex_scan_cols(int ncol, const double* __restrict__ coltot,
+        double* __restrict__ coloff, const MemberState* __restrict__ st)
 {
     __shared__ double part[1024];
     const int m = blockIdx.x;
     if (st && !st[m].active) return;
-    const double* sg = sigma + (size_t)m * nchunk;
-    double* pf = prefix + (size_t)m * nchunk;
-    const int per = (nchunk + 1023) / 1024;
-    const int lo = min(nchunk, (int)threadIdx.x * per), hi = min(nchunk, lo + per);
+    const double* ct = coltot + (size_t)m * ncol;
+    double* co = coloff + (size_t)m * ncol;
+    const int per = (ncol + 1023) / 1024;
+    const int lo = min(ncol, (int)threadIdx.x * per), hi = min(ncol, lo + per);
     double loc = 0.0;
-    for (int k = lo; k < hi; ++k) loc += sg[k];
+    for (int k = lo; k < hi; ++k) loc += ct[k];
     part[threadIdx.x] = loc;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {               // Hillis-Steele inclusive scan
@@ -102,14 +166,14 @@ __global__ __launch_bounds__(1024) void k_ex_scan(int nchunk, const double* __re
         part[threadIdx.x] += v;
         __syncthreads();
     }
-    double run = part[threadIdx.x] - loc;                    // exclusive prefix of this thread's range
-    for (int k = lo; k < hi; ++k) { pf[k] = run; run += sg[k]; }
+    double run = part[threadIdx.x] - loc;
+    for (int k = lo; k < hi; ++k) { co[k] = run; run += ct[k]; }
 }
 
 // C. exact ulp counts of each chunk for its predicted binade
 __global__ __launch_bounds__(256) void k_ex_chunk_summaries(Grid g, const float* __restrict__ R, int ncol, int nseg,
-        int nrows, const double* __restrict__ prefix, ExactSum* __restrict__ chunk,
-        const MemberState* __restrict__ st)
+        int nrows, const double* __restrict__ prefix, const double* __restrict__ coloff,
+        ExactSum* __restrict__ chunk, const MemberState* __restrict__ st)
 {
     const int m = blockIdx.z;
     if (st && !st[m].active) return;
@@ -117,40 +181,13 @@ __global__ __launch_bounds__(256) void k_ex_chunk_summaries(Grid g, const float*
     const int seg = blockIdx.y * 4 + threadIdx.y;
     if (col >= ncol || seg >= nseg) return;
     const size_t c = (size_t)m * ncol * nseg + (size_t)col * nseg + seg;
-    const ChunkAddr a = chunk_addr(g, R + (size_t)m * g.plane, col, seg, nrows);
+    const double P = coloff[(size_t)m * ncol + col] + prefix[c];
     ExactSum out;
-    out.ke = 0; out.ko = 0; out.valid = 1;
-    const double P = prefix[c];
     if (!(P >= 0.0) || !(P < 3.0e38)) {                      // NaN / Inf / overflowing prediction
-        out.eu = -100000; out.valid = 0;
-        chunk[c] = out;
-        return;
+        out.ke = 0; out.ko = 0; out.eu = -100000; out.valid = 0;
+    } else {
+        out = chunk_summary(chunk_addr(g, R + (size_t)m * g.plane, col, seg, nrows), g.pitch, ulp_exp(f2u((float)P)));
     }
-    const int eu = ulp_exp(f2u((float)P));
-    out.eu = eu;
-    unsigned ke = 0, ko = 0;
-    bool ok = true;
-    for (int r = 0; r < a.n; ++r) {
-        const float x = a.p[(size_t)r * g.pitch];
-        const unsigned tb = f2u(x * x);                      // to_dat(i,j)**2.0, >= +0
-        const unsigned Et = (tb >> 23) & 0xffu;
-        const unsigned fr = tb & 0x7fffffu;
-        if (Et == 255u) { ok = false; break; }               // Inf / NaN term: genuine adds only
-        const unsigned Mt = Et ? (fr | 0x800000u) : fr;
-        if (Mt == 0u) continue;                              // + 0
-        const int shift = eu - ((int)(Et ? Et : 1u) - 150);
-        if (shift <= 0) { ok = false; break; }               // term >= 2^23 ulps: leaves the binade
-        if (shift >= 25) continue;                           // < half an ulp: absorbed
-        const unsigned q = Mt >> shift;
-        const unsigned rem = Mt & ((1u << shift) - 1u);
-        const unsigned half = 1u << (shift - 1);
-        const unsigned up_e = (rem > half) || (rem == half && ((ke + q) & 1u));
-        const unsigned up_o = (rem > half) || (rem == half && (((ko + q) & 1u) ^ 1u));
-        ke += q + up_e;
-        ko += q + up_o;
-    }
-    if (!ok || ke >= (1u << 24) || ko >= (1u << 24)) { out.valid = 0; ke = 0; ko = 0; }
-    out.ke = ke; out.ko = ko;
     chunk[c] = out;
 }
 
@@ -164,55 +201,77 @@ __global__ __launch_bounds__(256) void k_ex_col_summaries(int ncol, int nseg, co
     if (col >= ncol) return;
     const ExactSum* cs = chunk + ((size_t)m * ncol + col) * nseg;
     ExactSum out = cs[0];
-    unsigned ke = out.ke, ko = out.ko;
-    bool ok = out.valid != 0;
-    for (int k = 1; k < nseg && ok; ++k) {
-        const ExactSum b = cs[k];
-        if (!b.valid || b.eu != out.eu) { ok = false; break; }
-        // incoming parity p, after the prefix the parity is p ^ (K_prefix & 1)
-        ke += ((ke & 1u) ? b.ko : b.ke);
-        ko += (((ko & 1u) ^ 1u) ? b.ko : b.ke);
-        if (ke >= (1u << 24) || ko >= (1u << 24)) ok = false;
-    }
-    out.valid = ok ? 1 : 0;
-    out.ke = ok ? ke : 0;
-    out.ko = ok ? ko : 0;
+    for (int k = 1; k < nseg && out.valid; ++k) out = compose(out, cs[k]);
     colsum[(size_t)m * ncol + col] = out;
 }
 
-// E. the walk: one wave per member, every lane carries the same (wave-uniform) state
+// E. the walk: one wave per member; the state `bits` is wave-uniform
 __global__ __launch_bounds__(64) void k_ex_walk(Grid g, const float* __restrict__ R, int ncol, int nseg, int nrows,
         const ExactSum* __restrict__ chunk, const ExactSum* __restrict__ colsum, float* __restrict__ out,
-        int* __restrict__ slow_chunks, const MemberState* __restrict__ st)
+        int* __restrict__ slow_chunks, const MemberState* __restrict__ st, int cols_in_lds)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int rep_of[MAXREP];       // staged column ids
+    __shared__ int nrep_s;
     const int m = blockIdx.x;
     if (st && !st[m].active) return;
     const int lane = threadIdx.x;
     const float* Rm = R + (size_t)m * g.plane;
-    const ExactSum* cols = colsum + (size_t)m * ncol;
+    const ExactSum* cols_g = colsum + (size_t)m * ncol;
+    ExactSum* cols_l = reinterpret_cast<ExactSum*>(smem);                         // [cols_in_lds ? ncol : 0]
+    ExactSum* rep_l = cols_l + (cols_in_lds ? ncol : 0);                          // [MAXREP][nseg]
+
+    // stage the column summaries, and the chunk summaries of the columns that will need a descent
+    if (lane == 0) nrep_s = 0;
+    __syncthreads();
+    // (loads are issued in batches of 8 per lane so that their latencies overlap)
+    if (cols_in_lds) {
+        for (int base = 0; base < ncol; base += 64 * 8) {
+            ExactSum tmp[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int c = base + u * 64 + lane; tmp[u] = c < ncol ? cols_g[c] : ExactSum{0u, 0u, 0, 1}; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = base + u * 64 + lane;
+                if (c < ncol) {
+                    cols_l[c] = tmp[u];
+                    if (!tmp[u].valid) { const int slot = atomicAdd(&nrep_s, 1); if (slot < MAXREP) rep_of[slot] = c; }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int nrep = cols_in_lds ? min(nrep_s, MAXREP) : 0;
+    const int nstage = nrep * nseg;
+    for (int base = 0; base < nstage; base += 64 * 8) {
+        ExactSum tmp[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = base + u * 64 + lane;
+            if (e < nstage) tmp[u] = chunk[((size_t)m * ncol + rep_of[e / nseg]) * nseg + e % nseg];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int e = base + u * 64 + lane; if (e < nstage) rep_l[e] = tmp[u]; }
+    }
+    __syncthreads();
+    const ExactSum* cols = cols_in_lds ? cols_l : cols_g;
+
     unsigned bits = 0u;                                       // err_now = 0
     int slow = 0;
 
-    // Take as many of the next (up to 64) summaries as fit, in ONE step: lane l loads summary base+l,
-    // an inclusive wave scan composes them (composition of (K_even,K_odd) maps is associative), so
-    // lane l holds the summary of the run [base, base+l]; runs that are valid for the current binade
-    // and keep the sum inside it form a prefix (K only grows); the longest one is applied.
-    // Returns how many summaries were consumed (0: the first one itself does not fit).
-    auto take_run = [&](const ExactSum* src, int base, int count) -> int {
-        ExactSum me;
-        if (base + lane < count) me = src[base + lane];
-        else { me.ke = 0; me.ko = 0; me.eu = 0; me.valid = 0; }
+    // lane l holds summary number l of a window; after the inclusive scan it holds the run [0..l].
+    // Runs that are valid for the current binade and keep the sum inside it form a prefix (K only
+    // grows); the longest is applied.  Returns how many summaries were consumed.
+    auto scan_take = [&](ExactSum me) -> int {
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
-            ExactSum a;                                       // the run that ends `off` lanes earlier
-            a.ke = __shfl_up(me.ke, off, 64); a.ko = __shfl_up(me.ko, off, 64);
-            a.eu = __shfl_up(me.eu, off, 64); a.valid = __shfl_up(me.valid, off, 64);
-            if (lane >= off) {
-                const unsigned ke = a.ke + ((a.ke & 1u) ? me.ko : me.ke);
-                const unsigned ko = a.ko + (((a.ko & 1u) ^ 1u) ? me.ko : me.ke);
-                const bool ok = a.valid && me.valid && a.eu == me.eu && ke < (1u << 24) && ko < (1u << 24);
-                me.ke = ok ? ke : 0u; me.ko = ok ? ko : 0u; me.valid = ok ? 1 : 0;
-            }
+            // two shuffles per step: ke (24 bits) | eu+149 (8 bits), ko (24 bits) | valid
+            const unsigned w0 = __shfl_up(me.ke | ((unsigned)(me.eu + 149) << 24), off, 64);
+            const unsigned w1 = __shfl_up(me.ko | ((unsigned)me.valid << 24), off, 64);
+            ExactSum a;
+            a.ke = w0 & 0xffffffu; a.eu = (int)(w0 >> 24) - 149;
+            a.ko = w1 & 0xffffffu; a.valid = (int)(w1 >> 24);
+            if (lane >= off) me = compose(a, me);
         }
         const unsigned nb = bits + ((bits & 1u) ? me.ko : me.ke);
         const unsigned e0 = bits >> 23, e1 = nb >> 23;
@@ -223,24 +282,40 @@ __global__ __launch_bounds__(64) void k_ex_walk(Grid g, const float* __restrict_
         if (n > 0) bits = __shfl(nb, n - 1, 64);
         return n;
     };
+    const ExactSum none = {0u, 0u, 0, 0};
 
     for (int col = 0; col < ncol;) {
-        const int n = take_run(cols, col, ncol);
+        const int n = scan_take(col + lane < ncol ? cols[col + lane] : none);
         col += n;
-        if (n > 0 || col >= ncol) continue;
-        // column `col` does not fit as a whole: same game over its chunks
+        if (n == 64 || col >= ncol) continue;
+        // column `col` is the first of the window that does not fit as a whole: the same game over its chunks
         const ExactSum* ch = chunk + ((size_t)m * ncol + col) * nseg;
+        for (int k = 0; k < nrep; ++k) if (rep_of[k] == col) ch = rep_l + (size_t)k * nseg;   // staged copy
         for (int seg = 0; seg < nseg;) {
-            const int k = take_run(ch, seg, nseg);
-            seg += k;
-            if (k > 0 || seg >= nseg) continue;
-            // chunk `seg` does not fit (binade crossing, a term above half the sum, Inf/NaN):
+            const int eu_now = ulp_exp(bits);
+            ExactSum me = none;
+            if (seg + lane < nseg) me = ch[seg + lane];
+            // A summary stored for another binade cannot be used now.  If that already holds for the
+            // FIRST chunk of the window the prediction was off here: recount the window for the real
+            // binade.  Otherwise the later chunks simply lie beyond a crossing that is still ahead.
+            const bool stale = (seg + lane < nseg) && me.eu != eu_now;
+            if (__shfl((int)stale, 0, 64)) {
+                if (stale) me = chunk_summary(chunk_addr(g, Rm, col, seg + lane, nrows), g.pitch, eu_now);
+            } else if (stale) {
+                me = none;
+            }
+            seg += scan_take(me);
+            if (seg >= nseg) break;
+            // chunk `seg` does not fit this binade (crossing, a term above half the sum, Inf/NaN):
             // genuine sequential fp32 additions -- lanes fetch, the sum runs in reference order
             const ChunkAddr a = chunk_addr(g, Rm, col, seg, nrows);
             float t = 0.0f;
             if (lane < a.n) { const float x = a.p[(size_t)lane * g.pitch]; t = x * x; }
             float sacc = u2f(bits);
-            for (int r = 0; r < a.n; ++r) sacc = sacc + __shfl(t, r, 64);
+            const int tb = (int)f2u(t);
+#pragma unroll
+            for (int r = 0; r < SEG; ++r)                      // v_readlane with a constant lane: no LDS round trip
+                if (r < a.n) sacc = sacc + u2f((unsigned)__builtin_amdgcn_readlane(tb, r));
             bits = f2u(sacc);
             ++slow;
             ++seg;
@@ -260,7 +335,13 @@ size_t exact_ws_bytes(const Grid& g)
     const int ncol = g.nx - 2, nrows = g.ny - 2;
     const int nseg = (nrows + SEG - 1) / SEG;
     const size_t nchunk = (size_t)ncol * nseg;
-    return (size_t)g.members * (nchunk * (2 * sizeof(double) + sizeof(ExactSum)) + (size_t)ncol * sizeof(ExactSum)) + 256;
+    return (size_t)g.members * (nchunk * (sizeof(double) + sizeof(ExactSum)) + (size_t)ncol * (2 * sizeof(double) + sizeof(ExactSum))) + 256;
+}
+
+int exact_kernel_setup()
+{
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ex_walk),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
 }
 
 void launch_exact_sumsq(const Grid& g, const float* R, void* workspace, float* out_sums, int* slow_chunks,
@@ -271,16 +352,23 @@ void launch_exact_sumsq(const Grid& g, const float* R, void* workspace, float* o
     const size_t nchunk = (size_t)ncol * nseg;
     char* w = static_cast<char*>(workspace);
     double* sigma = reinterpret_cast<double*>(w);               w += (size_t)g.members * nchunk * sizeof(double);
-    double* prefix = reinterpret_cast<double*>(w);              w += (size_t)g.members * nchunk * sizeof(double);
+    double* coltot = reinterpret_cast<double*>(w);              w += (size_t)g.members * ncol * sizeof(double);
+    double* coloff = reinterpret_cast<double*>(w);              w += (size_t)g.members * ncol * sizeof(double);
     ExactSum* chunk = reinterpret_cast<ExactSum*>(w);           w += (size_t)g.members * nchunk * sizeof(ExactSum);
     ExactSum* colsum = reinterpret_cast<ExactSum*>(w);
     const dim3 gc((ncol + 63) / 64, (nseg + 3) / 4, g.members), bc(64, 4, 1);
+    const dim3 gcol((ncol + 255) / 256, g.members);
     hipLaunchKernelGGL(k_ex_chunk_sums, gc, bc, 0, s, g, R, ncol, nseg, nrows, sigma, st);
-    hipLaunchKernelGGL(k_ex_scan, dim3(g.members), dim3(1024), 0, s, (int)nchunk, sigma, prefix, st);
-    hipLaunchKernelGGL(k_ex_chunk_summaries, gc, bc, 0, s, g, R, ncol, nseg, nrows, prefix, chunk, st);
-    hipLaunchKernelGGL(k_ex_col_summaries, dim3((ncol + 255) / 256, g.members), dim3(256), 0, s, ncol, nseg, chunk, colsum, st);
-    hipLaunchKernelGGL(k_ex_walk, dim3(g.members), dim3(64), 0, s, g, R, ncol, nseg, nrows, chunk, colsum, out_sums,
-                       slow_chunks, st);
+    hipLaunchKernelGGL(k_ex_col_prefix, gcol, dim3(256), 0, s, ncol, nseg, sigma, coltot, st);
+    hipLaunchKernelGGL(k_ex_scan_cols, dim3(g.members), dim3(1024), 0, s, ncol, coltot, coloff, st);
+    hipLaunchKernelGGL(k_ex_chunk_summaries, gc, bc, 0, s, g, R, ncol, nseg, nrows, sigma, coloff, chunk, st);
+    hipLaunchKernelGGL(k_ex_col_summaries, gcol, dim3(256), 0, s, ncol, nseg, chunk, colsum, st);
+    // LDS: all column summaries + the chunk summaries of up to MAXREP columns, when that fits
+    size_t lds = ((size_t)ncol + (size_t)MAXREP * nseg) * sizeof(ExactSum);
+    int cols_in_lds = 1;
+    if (lds > 150 * 1024) { lds = 0; cols_in_lds = 0; }
+    hipLaunchKernelGGL(k_ex_walk, dim3(g.members), dim3(64), lds, s, g, R, ncol, nseg, nrows, chunk, colsum, out_sums,
+                       slow_chunks, st, cols_in_lds);
 }
 
 }  // namespace xee
