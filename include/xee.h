@@ -203,6 +203,10 @@ int xee_ensemble_device_plane(xee_ensemble_t *ens, int field, void **dptr, int *
                               size_t *member_stride, int *n1, int *n2);
 /* f := -rhoB_in (DYNAMIC_EFFICIENCY, initialize-variables.f90:40-42) */
 int xee_ensemble_forcing_from_B(xee_ensemble_t *ens);
+/* f := g0/theta0 * d/dr( Q/(Cp*exner) ) averaged to O points, from the uploaded Q (B cells): the thermal
+ * source term of the legacy sweep, old-diagnose/diagnose.f90:383-387,395-406;  f := 0 (:553) */
+int xee_ensemble_forcing_thermal(xee_ensemble_t *ens);
+int xee_ensemble_forcing_zero(xee_ensemble_t *ens);
 /* solver coefficients (K1) then the 9-point stencil (K2) for the chosen operator variant */
 int xee_ensemble_assemble(xee_ensemble_t *ens, int variant);
 /* strf := bc_init_in, then solve_elliptic on every member; per-member results in the records */

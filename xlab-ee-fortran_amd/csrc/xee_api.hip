@@ -409,6 +409,23 @@ int xee_ensemble_forcing_from_B(xee_ensemble_t* e)
     return check_launch("negate");
 }
 
+int xee_ensemble_forcing_thermal(xee_ensemble_t* e)
+{
+    XCHK(use(e));
+    if (!e->have_profiles) return fail(XEE_ERR_INVALID_ARGUMENT, "profiles not set");
+    if (!e->Q) return fail(XEE_ERR_INVALID_ARGUMENT, "Q has not been uploaded");
+    XCHK(alloc_planes(e, &e->terms));
+    launch_rhs_thermal(e->g, e->Q, e->ra, e->exner, e->terms, e->f, e->stream);
+    return check_launch("forcing_thermal");
+}
+
+int xee_ensemble_forcing_zero(xee_ensemble_t* e)
+{
+    XCHK(use(e));
+    HIPCHK(hipMemsetAsync(e->f, 0, sizeof(float) * e->g.plane * e->g.members, e->stream));
+    return XEE_OK;
+}
+
 int xee_ensemble_assemble(xee_ensemble_t* e, int variant)
 {
     XCHK(use(e));

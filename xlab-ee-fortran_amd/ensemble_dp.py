@@ -18,23 +18,29 @@ def partition(n_cases, world, rank):
     return lo, min(n_cases, lo + per)
 
 
-def gather_records(records, n_cases, world, rank, device=None):
-    """records: this rank's numpy structured array (RECORD_DTYPE, 128 B each, possibly fewer than
-    ceil(N/G) on the last rank).  Returns all n_cases records ordered by case (every rank gets them).
+def gather_records(records, n_cases, world, rank, device=None, per_rank=None):
+    """records: this rank's numpy structured array (RECORD_DTYPE, 128 B each, case_id >= 0), in
+    ascending case order; ranks hold consecutive blocks.  Every rank gets all n_cases records ordered
+    by rank block.  `per_rank` = the largest number of records any rank holds (default
+    ceil(n_cases/world)); shorter ranks are padded with case_id = -1 records, dropped after the gather.
     world == 1 needs no process group."""
     import torch
-    per = -(-n_cases // world)
     dtype = records.dtype
     assert dtype.itemsize == RECORD_BYTES
     if world == 1:
         return records.copy()
     import torch.distributed as dist
-    buf = np.zeros((per, RECORD_BYTES), np.uint8)              # pad the tail rank
-    buf[: len(records)] = records.view(np.uint8).reshape(len(records), RECORD_BYTES)
-    send = torch.from_numpy(buf)
+    per = per_rank if per_rank is not None else -(-n_cases // world)
+    assert len(records) <= per
+    pad = np.zeros(per, dtype)
+    pad["case_id"] = -1
+    pad[: len(records)] = records
+    send = torch.from_numpy(pad.view(np.uint8).reshape(per, RECORD_BYTES))
     if device is not None:
         send = send.to(device)
     recv = torch.empty((world * per, RECORD_BYTES), dtype=torch.uint8, device=send.device)
     dist.all_gather_into_tensor(recv, send)
-    out = recv.cpu().numpy().reshape(-1)[: n_cases * RECORD_BYTES].copy()
-    return out.view(dtype)
+    out = recv.cpu().numpy().reshape(-1).view(dtype)
+    out = out[out["case_id"] >= 0].copy()
+    assert len(out) == n_cases, (len(out), n_cases)
+    return out

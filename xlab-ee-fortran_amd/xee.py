@@ -93,6 +93,8 @@ def lib():
     L.xee_ensemble_download.argtypes = [vp, C.c_int, C.c_int, C.c_int, _f32p]
     L.xee_ensemble_device_plane.argtypes = [vp, C.c_int, C.POINTER(vp), _pi, C.POINTER(C.c_size_t), _pi, _pi]
     L.xee_ensemble_forcing_from_B.argtypes = [vp]
+    L.xee_ensemble_forcing_thermal.argtypes = [vp]
+    L.xee_ensemble_forcing_zero.argtypes = [vp]
     L.xee_ensemble_assemble.argtypes = [vp, C.c_int]
     L.xee_ensemble_solve.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int]
     L.xee_ensemble_cal_eta.argtypes = [vp]
@@ -298,6 +300,12 @@ class Ensemble:
 
     def forcing_from_B(self):
         _chk(lib().xee_ensemble_forcing_from_B(self._h))
+
+    def forcing_thermal(self):
+        _chk(lib().xee_ensemble_forcing_thermal(self._h))
+
+    def forcing_zero(self):
+        _chk(lib().xee_ensemble_forcing_zero(self._h))
 
     def assemble(self, variant):
         _chk(lib().xee_ensemble_assemble(self._h, variant))
