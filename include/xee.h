@@ -212,6 +212,12 @@ int xee_ensemble_assemble(xee_ensemble_t *ens, int variant);
 /* strf := bc_init_in, then solve_elliptic on every member; per-member results in the records */
 int xee_ensemble_solve(xee_ensemble_t *ens, int max_iter, int check_step, int converge_time,
                        int lost_rate, float strategy_r1, float strategy_r2, float alpha, int flags);
+/* OPT-IN, NON-PARITY smoother (the "red/black SOR" the north star words): 4-colour
+ * successive over-relaxation, 0 < omega < 2, same stopping rule and records as xee_ensemble_solve but the
+ * check uses the residual of the current iterate.  Converges to the same fixed point in far fewer
+ * iterations; its iterates are NOT the reference's, so parity holds only to solver tolerance. */
+int xee_ensemble_solve_sor(xee_ensemble_t *ens, int max_iter, int check_step, int converge_time,
+                           int lost_rate, float strategy_r1, float strategy_r2, float omega, int flags);
 int xee_ensemble_cal_eta(xee_ensemble_t *ens);
 int xee_ensemble_cal_uw(xee_ensemble_t *ens);
 /* sum_Q, sum_Qeta, efficiency from Q and the current eta (order-exact fp32 sums) */

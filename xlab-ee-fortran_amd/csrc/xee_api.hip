@@ -549,6 +549,71 @@ int xee_ensemble_solve(xee_ensemble_t* e, int max_iter, int check_step, int conv
     return XEE_OK;
 }
 
+// OPT-IN, NON-PARITY: 4-colour SOR with the reference's stopping rule.  The
+// check at a multiple of check_step uses the residual of the CURRENT iterate.  Iterates differ from
+// the reference's Jacobi; the fixed point is the same.
+int xee_ensemble_solve_sor(xee_ensemble_t* e, int max_iter, int check_step, int converge_time, int lost_rate,
+                           float r1, float r2, float omega, int flags)
+{
+    XCHK(use(e));
+    const bool chk_abs = r1 > 0.0f, chk_rel = r2 > 0.0f;
+    if (!chk_abs && !chk_rel)
+        return fail(XEE_ERR_INVALID_CRITERIA, "[check_abs_err] and [check_rel_err] cannot both be non-positive.");
+    if (max_iter < 0 || !(omega > 0.0f && omega < 2.0f)) return fail(XEE_ERR_INVALID_ARGUMENT, "need max_iter >= 0 and 0 < omega < 2");
+    ConvParams cp{};
+    cp.r1 = chk_abs ? r1 : FLT_MAX;
+    cp.r2 = chk_rel ? r2 : FLT_MAX;
+    const int cs = check_step > 0 ? check_step : 100;
+    cp.converge_time = converge_time > 0 ? converge_time : 10;
+    cp.lost_rate = lost_rate > 0 ? lost_rate : 5;
+    cp.n_interior = (e->g.nx - 2) * (e->g.ny - 2);
+    cp.debug = (flags & XEE_SOLVE_TRACE) ? 2 : 0;
+    const Grid& g = e->g;
+    hipStream_t s = e->stream;
+    if (!(flags & XEE_SOLVE_KEEP_PSI)) { launch_copy2(g, e->bc, e->psi[0], e->psi[1], s); e->cur = 0; }
+    launch_state_init(g, e->st, s);
+    e->timing = xee_timing_t{};
+    HIPCHK(hipEventRecord(e->ev[0], s));
+    bool all_done = (max_iter == 0);
+    for (int cnt = 1; cnt <= max_iter && !all_done; ++cnt) {
+        launch_sor_iteration(g, e->psi[e->cur], e->coe, e->f, e->st, omega, s);
+        e->timing.sweep_launches += 4;
+        e->timing.iterations += 1;
+        const bool check = (cnt % cs) == 0, last = cnt == max_iter;
+        if (check) {
+            launch_residual(g, e->psi[e->cur], e->coe, e->f, e->res, e->st, s);
+            launch_exact_sumsq(g, e->res, e->ex_ws, e->sums, e->ex_slow, e->st, s);
+            cp.cnt = cnt;
+            cp.is_last = last ? 1 : 0;
+            launch_conv_update(g, e->sums, e->st, cp, s);
+            e->timing.check_launches += 1;
+        } else if (last) {
+            launch_finalize(g, e->st, max_iter, s);
+        }
+        if (check || last) {
+            XCHK(check_launch("sor/check"));
+            HIPCHK(hipMemcpyAsync(e->st_host, e->st, sizeof(MemberState) * g.members, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            all_done = true;
+            for (int m = 0; m < g.members; ++m) if (e->st_host[m].active) all_done = false;
+        }
+    }
+    HIPCHK(hipEventRecord(e->ev[1], s));
+    if (max_iter == 0) HIPCHK(hipMemcpyAsync(e->st_host, e->st, sizeof(MemberState) * g.members, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e->ev[0], e->ev[1]));
+    e->timing.solve_ms = ms;
+    for (int m = 0; m < g.members; ++m) {
+        xee_case_record_t& r = e->rec[m];
+        r.iters = e->st_host[m].iters;
+        r.err_bits = e->st_host[m].err_bits;
+        r.err_now = e->st_host[m].err_now;
+        r.ratio = e->st_host[m].ratio;
+    }
+    return XEE_OK;
+}
+
 int xee_ensemble_cal_eta(xee_ensemble_t* e)
 {
     XCHK(use(e));

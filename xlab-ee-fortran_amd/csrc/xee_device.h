@@ -81,6 +81,11 @@ void launch_sweep_tb(const Grid& g, const float* psi_in, float* psi_out, const f
                      const float* f, float* res /* residual of the LAST iteration, or nullptr */,
                      const MemberState* st, float alpha, int T, const UniformVals& uv, hipStream_t s);
 int  tb_max_T();
+// opt-in, non-parity: one 4-colour SOR iteration in place; residual plane of the current iterate
+void launch_sor_iteration(const Grid& g, float* psi, const float* coe, const float* f, const MemberState* st,
+                          float omega, hipStream_t s);
+void launch_residual(const Grid& g, const float* psi, const float* coe, const float* f, float* res,
+                     const MemberState* st, hipStream_t s);
 // sequential fp32 sum, reference loop order (i outer, j inner), of T or T*T over a sub-rectangle
 void launch_seqsum(const Grid& g, const float* T, int i0, int i1, int j0, int j1, bool square,
                    float* out_sums, const MemberState* st, hipStream_t s);

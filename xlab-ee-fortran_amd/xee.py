@@ -97,6 +97,7 @@ def lib():
     L.xee_ensemble_forcing_zero.argtypes = [vp]
     L.xee_ensemble_assemble.argtypes = [vp, C.c_int]
     L.xee_ensemble_solve.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int]
+    L.xee_ensemble_solve_sor.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int]
     L.xee_ensemble_cal_eta.argtypes = [vp]
     L.xee_ensemble_cal_uw.argtypes = [vp]
     L.xee_ensemble_ee_scalars.argtypes = [vp]
@@ -313,6 +314,12 @@ class Ensemble:
     def solve(self, max_iter, r1, r2, alpha, check_step=100, converge_time=10, lost_rate=5, flags=0):
         _chk(lib().xee_ensemble_solve(self._h, int(max_iter), check_step, converge_time, lost_rate,
                                       float(r1), float(r2), float(alpha), flags))
+        return self.records()
+
+    def solve_sor(self, max_iter, r1, r2, omega, check_step=100, converge_time=10, lost_rate=5, flags=0):
+        """Opt-in, non-parity 4-colour SOR (same fixed point, far fewer iterations)."""
+        _chk(lib().xee_ensemble_solve_sor(self._h, int(max_iter), check_step, converge_time, lost_rate,
+                                          float(r1), float(r2), float(omega), flags))
         return self.records()
 
     def cal_eta(self):
