@@ -78,6 +78,9 @@ struct xee_ensemble {
     void* ex_ws = nullptr;       // workspace of the parallel order-exact residual norm
     int* ex_slow = nullptr;      // per member: chunks the last check summed term by term
     bool exact_serial = false;   // XEE_EXACT_SUM=serial: single-lane reference-order walk instead
+    float* base = nullptr;       // the operator's four generating planes AP, CQ, BX, BY (xee_sweep4.hip)
+    bool have_base = false;      // they describe the current coefficient planes (set by assemble)
+    bool base_baro = false;      // ... of the BAROTROPIC operator (BX = BY = +0: not loaded)
     UniformVals uv{};            // coefficient planes found uniform by the last assemble / coe upload
     unsigned* uv_differs = nullptr;
 };
@@ -143,6 +146,7 @@ int check_launch(const char* what);
 int detect_uniform_planes(xee_ensemble* e)
 {
     e->uv = UniformVals{};
+    e->have_base = false;        // callers that also build the generating planes set it afterwards
     if (!e->uv_differs) HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->uv_differs), sizeof(unsigned)));
     launch_uniform_check(e->g, e->coe, e->uv_differs, e->stream);
     unsigned differs = 0x1ffu;
@@ -155,6 +159,17 @@ int detect_uniform_planes(xee_ensemble* e)
     e->uv.mask = (~differs) & 0x1ffu;
     for (int k = 0; k < 9; ++k) e->uv.v[k] = v[k];
     return XEE_OK;
+}
+
+// T iterations of the blocked sweep: from the four generating planes when assemble built them
+// (fewer bytes), else from the nine coefficient planes (any coefficients, e.g. a Tier-1 caller's)
+void launch_blocked(xee_ensemble* e, const float* psi_in, float* psi_out, float* res, float alpha, int T)
+{
+    const bool no_base4 = getenv("XEE_NO_BASE4") != nullptr;   // A/B switch for tests and probes
+    if (e->have_base && !no_base4)
+        launch_sweep_tb4(e->g, psi_in, psi_out, e->base, e->f, res, e->st, alpha, T, e->base_baro, e->stream);
+    else
+        launch_sweep_tb(e->g, psi_in, psi_out, e->coe, e->f, res, e->st, alpha, T, e->uv, e->stream);
 }
 
 int check_launch(const char* what)
@@ -306,6 +321,7 @@ int xee_ensemble_destroy(xee_ensemble_t* e)
     if (e->ex_ws) hipFree(e->ex_ws);
     if (e->ex_slow) hipFree(e->ex_slow);
     if (e->uv_differs) hipFree(e->uv_differs);
+    if (e->base) hipFree(e->base);
     if (e->st_host) hipHostFree(e->st_host);
     if (e->sums_host) hipHostFree(e->sums_host);
     for (auto& ev : e->ev) if (ev) hipEventDestroy(ev);
@@ -362,7 +378,7 @@ static int xfer(xee_ensemble_t* e, int field, int first, int count, float* host,
     float* base = nullptr;
     int n1 = 0, n2 = 0;
     XCHK(field_ref(e, field, &base, &n1, &n2));
-    if (up && field >= XEE_F_COE0) e->uv.mask = 0;   // planes changed behind assemble's back: assume nothing
+    if (up && field >= XEE_F_COE0) { e->uv.mask = 0; e->have_base = false; }   // planes changed behind assemble's back: assume nothing
     for (int k = 0; k < count; ++k) {
         float* d = base + (size_t)(first + k) * e->g.plane;
         float* h = host + (size_t)k * n1 * n2;
@@ -438,7 +454,13 @@ int xee_ensemble_assemble(xee_ensemble_t* e, int variant)
     launch_solver_coef(e->g, e->A, e->B, e->C, e->rcuva, e->rho, e->sA, e->sB, e->sC, e->stream);
     launch_cal_coe(e->g, e->sA, variant == XEE_BAROCLINIC ? e->sB : nullptr, e->sC, e->coe, e->dr, e->dz, e->stream);
     XCHK(check_launch("assemble"));
-    return detect_uniform_planes(e);
+    XCHK(detect_uniform_planes(e));
+    XCHK(alloc_planes(e, &e->base, 4));
+    launch_base_planes(e->g, e->sA, variant == XEE_BAROCLINIC ? e->sB : nullptr, e->sC, e->base, e->dr, e->dz, e->stream);
+    XCHK(check_launch("base planes"));
+    e->have_base = true;
+    e->base_baro = (variant == XEE_BAROTROPIC);
+    return XEE_OK;
 }
 
 // solve_elliptic, xtt-lib-fortran/elliptic_tools.f90:93-265, for every member at once.
@@ -488,7 +510,7 @@ int xee_ensemble_solve(xee_ensemble_t* e, int max_iter, int check_step, int conv
         if (n == 1)
             launch_sweep(g, e->psi[cur], e->psi[cur ^ 1], e->coe, e->f, check ? e->res : nullptr, e->st, alpha, s);
         else
-            launch_sweep_tb(g, e->psi[cur], e->psi[cur ^ 1], e->coe, e->f, check ? e->res : nullptr, e->st, alpha, n, e->uv, s);
+            launch_blocked(e, e->psi[cur], e->psi[cur ^ 1], check ? e->res : nullptr, alpha, n);
         cur ^= 1;
         e->timing.sweep_launches += 1;
         e->timing.iterations += n;
@@ -688,7 +710,7 @@ int xee_ensemble_time_sweeps(xee_ensemble_t* e, int iters, int variant, float al
     for (int k = 0; k < iters;) {
         const int n = variant == 0 ? 1 : ((iters - k) < e->tb_T ? (iters - k) : e->tb_T);
         if (n == 1) launch_sweep(g, e->psi[cur], e->psi[cur ^ 1], e->coe, e->f, nullptr, e->st, alpha, s);
-        else launch_sweep_tb(g, e->psi[cur], e->psi[cur ^ 1], e->coe, e->f, nullptr, e->st, alpha, n, e->uv, s);
+        else launch_blocked(e, e->psi[cur], e->psi[cur ^ 1], nullptr, alpha, n);
         cur ^= 1;
         k += n;
         ++nl;

@@ -80,6 +80,12 @@ void launch_uniform_check(const Grid& g, const float* coe, unsigned* differs /* 
 void launch_sweep_tb(const Grid& g, const float* psi_in, float* psi_out, const float* coe,
                      const float* f, float* res /* residual of the LAST iteration, or nullptr */,
                      const MemberState* st, float alpha, int T, const UniformVals& uv, hipStream_t s);
+// the same blocked sweep fed by the operator's four generating planes AP, CQ, BX, BY (xee_sweep4.hip):
+// base + k*members*plane, k = 0..3; the nine weights are rebuilt in the kernel prologue
+void launch_base_planes(const Grid& g, const float* sA, const float* sB /* nullptr: B = 0 */, const float* sC,
+                        float* base, float dx, float dy, hipStream_t s);
+void launch_sweep_tb4(const Grid& g, const float* psi_in, float* psi_out, const float* base, const float* f,
+                      float* res, const MemberState* st, float alpha, int T, bool barotropic, hipStream_t s);
 int  tb_max_T();
 // opt-in, non-parity: one 4-colour SOR iteration in place; residual plane of the current iterate
 void launch_sor_iteration(const Grid& g, float* psi, const float* coe, const float* f, const MemberState* st,
