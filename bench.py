@@ -182,7 +182,7 @@ def main():
         alg_bytes = BYTES_PER_POINT_ITER * interior * M * iters        # this rank, all timed steps
         achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
         tb_T = int(os.environ.get("XEE_TB_T", "6"))
-        kernel = "k_sweep_tb" if tb_T > 1 else "k_sweep_stream"
+        kernel = ("k_sweep_tb" if os.environ.get("XEE_NO_BASE4") else "k_sweep_tb4") if tb_T > 1 else "k_sweep_stream"
         out = {
             "metric": "diagnosed cases/s (1024x512 r-z grid, SOR to 1e-8)",
             "value": cases / dt, "unit": "cases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -24,13 +24,14 @@ namespace xee {
 
 namespace {
 
+// bound_ctrl: the lane without a source reads 0, so no `old` register has to be prepared
 __device__ __forceinline__ float shr1(float src)   // lane l <- lane l-1 (lane 0 gets 0)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src), 0x138, 0xf, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, src), 0x138, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float shl1(float src)   // lane l <- lane l+1 (lane 63 gets 0)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src), 0x130, 0xf, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, src), 0x130, 0xf, 0xf, true));
 }
 
 }  // namespace
@@ -125,42 +126,52 @@ __global__ __launch_bounds__(NW * 64) void k_sweep_tb4(Grid g, const float* __re
 
     // ---- T iterations (same as k_sweep_tb) ----------------------------------------------------
     const bool vx = (lane >= T || x0 <= 0) && (lane < 64 - T || x0 + 63 >= g.nx - 1);
-    for (int t = 0; t < T; ++t) {
+    // one Jacobi step src -> dst (two register sets, so no value has to be moved between iterations)
+    float q[R];
+    auto step = [&](const float (&src)[R], float (&dst)[R], int t) {
         const int par = t & 1;
-        edge[par][0][w][lane] = p[R - 1];
-        edge[par][1][w][lane] = p[0];
+        edge[par][0][w][lane] = src[R - 1];
+        edge[par][1][w][lane] = src[0];
         __syncthreads();
         const float below = (w > 0) ? edge[par][0][w - 1][lane] : 0.0f;
         const float above = (w < NW - 1) ? edge[par][1][w + 1][lane] : 0.0f;
-        float om = below, oml = shr1(om), omr = shl1(om);
-        float oc = p[0], ocl = shr1(oc), ocr = shl1(oc);
+        // the i-1 / i+1 views of rows -1..R of the old iterate, one DPP move each
+        float lft[R + 2], rgt[R + 2];
+        lft[0] = shr1(below); rgt[0] = shl1(below);
+#pragma unroll
+        for (int r = 0; r < R; ++r) { lft[r + 1] = shr1(src[r]); rgt[r + 1] = shl1(src[r]); }
+        lft[R + 1] = shr1(above); rgt[R + 1] = shl1(above);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const float on = (r + 1 < R) ? p[r + 1] : above;
-            const float onl = shr1(on), onr = shl1(on);
-            float Rv = c[0][r] * onl;                     // elliptic_tools.f90:77-85, left to right
+            const float om = (r > 0) ? src[r - 1] : below;
+            const float oc = src[r];
+            const float on = (r + 1 < R) ? src[r + 1] : above;
+            float Rv = c[0][r] * lft[r + 2];              // elliptic_tools.f90:77-85, left to right
             Rv = Rv + c[1][r] * on;
-            Rv = Rv + c[2][r] * onr;
-            Rv = Rv + c[3][r] * ocl;
+            Rv = Rv + c[2][r] * rgt[r + 2];
+            Rv = Rv + c[3][r] * lft[r + 1];
             Rv = Rv + c[4][r] * oc;
-            Rv = Rv + c[5][r] * ocr;
-            Rv = Rv + c[6][r] * oml;
+            Rv = Rv + c[5][r] * rgt[r + 1];
+            Rv = Rv + c[6][r] * lft[r];
             Rv = Rv + c[7][r] * om;
-            Rv = Rv + c[8][r] * omr;
+            Rv = Rv + c[8][r] * rgt[r];
             Rv = Rv - ff[r];                              // :190
             const float upd = oc + alpha * Rv / (-c[4][r]);   // :238
             const int gy = gy0 + r;
             const bool interior = col_int && gy >= 1 && gy <= g.ny - 2;
-            p[r] = interior ? upd : oc;
+            dst[r] = interior ? upd : oc;
             if (WRITE_R && t == T - 1) {
                 const int ly = w * R + r;
                 const bool vy = (ly >= T || y0 <= 0) && (ly < H - T || y0 + H - 1 >= g.ny - 1);
                 if (vx && vy && interior) res[mo + (size_t)gy * g.pitch + gx] = Rv;
             }
-            om = oc; oml = ocl; omr = ocr;
-            oc = on; ocl = onl; ocr = onr;
         }
+    };
+    for (int t = 0; t < T; t += 2) {
+        step(p, q, t);
+        if (t + 1 < T) step(q, p, t + 1);
     }
+    const bool in_q = (T & 1) != 0;                       // odd T: the last step wrote q
 
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -168,7 +179,7 @@ __global__ __launch_bounds__(NW * 64) void k_sweep_tb4(Grid g, const float* __re
         const int gy = gy0 + r;
         const bool vy = (ly >= T || y0 <= 0) && (ly < H - T || y0 + H - 1 >= g.ny - 1);
         const bool interior = col_int && gy >= 1 && gy <= g.ny - 2;
-        if (vx && vy && interior) psi_out[mo + (size_t)gy * g.pitch + gx] = p[r];
+        if (vx && vy && interior) psi_out[mo + (size_t)gy * g.pitch + gx] = in_q ? q[r] : p[r];
     }
 }
 
