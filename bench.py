@@ -72,26 +72,16 @@ def cpu_baseline(nr, nz, max_iter, sample_iters):
     sA, sB, sC = H.solver_coefficients(A, B, Cc, prof["rcuva"], prof["rho"])
     coe = H.cal_coe(sA, np.zeros_like(sB), sC, prof["dr"], prof["dz"], nr, nz)
     f = (-B).astype(np.float32)
-    devnull = os.open(os.devnull, os.O_WRONLY)
-    saved = os.dup(1)
-    sys.stdout.flush()
-    os.dup2(devnull, 1)                      # the reference prints "Elliptic Tools: ..." per call
-    try:
-        if H.have_ref():
-            kind = "reference"
-            t0 = time.perf_counter()
-            H.ref_solve(bc, coe, f, sample_iters, 1e-8, -1.0, 1.0)
-            dt = time.perf_counter() - t0
-        else:
-            kind = "port"
-            t0 = time.perf_counter()
-            H.solve(bc, coe, f, sample_iters, 1e-8, -1.0, 1.0, reforder=True)
-            dt = time.perf_counter() - t0
-    finally:
-        sys.stdout.flush()
-        os.dup2(saved, 1)
-        os.close(devnull)
-        os.close(saved)
+    if H.have_ref():
+        kind = "reference"
+        t0 = time.perf_counter()
+        H.ref_solve(bc, coe, f, sample_iters, 1e-8, -1.0, 1.0)
+        dt = time.perf_counter() - t0
+    else:
+        kind = "port"
+        t0 = time.perf_counter()
+        H.solve(bc, coe, f, sample_iters, 1e-8, -1.0, 1.0, reforder=True)
+        dt = time.perf_counter() - t0
     per_iter = dt / sample_iters
     return {"value": 1.0 / (per_iter * max_iter), "unit": "cases/s", "cores": 1, "kind": kind,
             "sample": f"solve_elliptic on one {nr}x{nz} case, {sample_iters} iterations in {dt:.2f} s "
@@ -110,7 +100,15 @@ def main():
     ap.add_argument("--max-iter", type=int, default=100000)
     ap.add_argument("--cpu-sample-iters", type=int, default=500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="ensemble", choices=["ensemble", "single", "highres", "baroclinic"],
+                    help="ensemble (default: the bench line) | single (configs[1]: one case) | highres (configs[3]: one "
+                         "4096x2048 case, 2,000 iterations) | baroclinic (the ensemble with the full-B operator)")
     args = ap.parse_args()
+    if args.workload == "single":
+        args.members = 1
+    elif args.workload == "highres":
+        args.members, args.nr, args.nz, args.max_iter = 1, 4096, 2048, 2000
+        args.cpu_sample_iters = min(args.cpu_sample_iters, 20)
 
     import torch
     import torch.distributed as dist
@@ -143,7 +141,7 @@ def main():
 
     def step():
         ens.forcing_from_B()                   # A7
-        ens.assemble(xee.BAROTROPIC)           # K1 + K2
+        ens.assemble(xee.BAROCLINIC if args.workload == "baroclinic" else xee.BAROTROPIC)   # K1 + K2
         ens.solve(args.max_iter, 1e-8, -1.0, 1.0, check_step=100, converge_time=10, lost_rate=5)   # K3 + K4
         ens.cal_eta()                          # K5
         rec = ens.ee_scalars()                 # K8
@@ -188,9 +186,11 @@ def main():
             "value": cases / dt, "unit": "cases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{M} independent {nr}x{nz} cases per GPU (x8 GPUs = the 256-member ensemble of "
-                                   f"configs[2]); each case = configs[1]: K1+K2+solve_elliptic(r1=1e-8, r2 off, alpha=1, "
-                                   f"max_iter={args.max_iter}, check every 100)+cal_eta+EE scalars",
+            "config": {"workload": f"[{args.workload}] {M} independent {nr}x{nz} case(s) per GPU"
+                                   + (" (x8 GPUs = the 256-member ensemble of configs[2])" if args.workload == "ensemble" else "")
+                                   + f"; each case = configs[1]: K1+K2+solve_elliptic(r1=1e-8, r2 off, alpha=1, "
+                                   f"max_iter={args.max_iter}, check every 100)+cal_eta+EE scalars; operator "
+                                   + ("BAROCLINIC (full B)" if args.workload == "baroclinic" else "BAROTROPIC (B=0)"),
                        "nr": nr, "nz": nz, "members_per_gpu": M, "max_iter": args.max_iter,
                        "solver": "damped Jacobi, bit-identical to the reference (SURVEY.md finding 1)",
                        "parallelism": f"ensemble-dp{world}"},
@@ -205,7 +205,19 @@ def main():
                          "avg_launch_us": sweep_ms * 1e3 / max(launches, 1), "launches": launches},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(nr, nz, args.max_iter, args.cpu_sample_iters)
+            # in a child process: the reference prints "Elliptic Tools: ..." through the Fortran runtime's own
+            # buffer, which is flushed at exit -- it must not land on this process's stdout (ONE JSON line)
+            import subprocess
+            code = ("import json, sys; sys.path.insert(0, %r); import bench; "
+                    "r = bench.cpu_baseline(%d, %d, %d, %d); sys.stdout.flush(); "
+                    "sys.stderr.write('XEE_CPU_BASELINE ' + json.dumps(r) + '\\n')"
+                    % (str(ROOT), nr, nz, args.max_iter, args.cpu_sample_iters))
+            p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+            for line in p.stderr.splitlines():
+                if line.startswith("XEE_CPU_BASELINE "):
+                    out["cpu_baseline"] = json.loads(line[len("XEE_CPU_BASELINE "):])
+            if "cpu_baseline" not in out:
+                raise SystemExit("cpu_baseline child failed:\n" + p.stderr[-2000:])
         print(json.dumps(out), flush=True)
     ens.close()
     if world > 1:

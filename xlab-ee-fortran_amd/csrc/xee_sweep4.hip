@@ -224,7 +224,7 @@ void launch_sweep_tb4(const Grid& g, const float* psi_in, float* psi_out, const 
         TB4_CASE(16, 8)
         default:
             if (barotropic) launch_tb4_cfg<8, 8, true>(g, psi_in, psi_out, base, f, res, st, alpha, T, s);
-            else launch_tb4_cfg<4, 16, false>(g, psi_in, psi_out, base, f, res, st, alpha, T, s);
+            else launch_tb4_cfg<8, 8, false>(g, psi_in, psi_out, base, f, res, st, alpha, T, s);
     }
 #undef TB4_CASE
 }
