@@ -1,0 +1,63 @@
+"""The residual checks run pipelined behind the sweeps by default (the check of iteration k is evaluated
+while the next block already iterates; results of members that stop come from a snapshot).  It must give
+exactly what the synchronous driver (XEE_SYNC_CHECKS=1) and the oracle give -- iteration counts, fields,
+residues -- for members stopping at different checks, at max_iter on and off a check boundary."""
+import numpy as np
+import pytest
+
+import orchelp as H
+import xee_pkg
+
+pytestmark = pytest.mark.gpu
+
+xee = xee_pkg.load()
+
+
+def biteq(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def run(A, B, Cc, bc, cfg, sync, monkeypatch):
+    if sync:
+        monkeypatch.setenv("XEE_SYNC_CHECKS", "1")
+    else:
+        monkeypatch.delenv("XEE_SYNC_CHECKS", raising=False)
+    return xee.diagnose_case(A, B, Cc, bc, **cfg)["BAROTROPIC"]
+
+
+@pytest.mark.parametrize("max_iter", [20000, 437, 300, 57])
+def test_pipelined_equals_synchronous_and_oracle(max_iter, monkeypatch):
+    nr, nz, M = 96, 64, 7
+    ins = [H.member_inputs(nr, nz, m) for m in range(M)]
+    A, B, Cc, bc = (np.stack([x[k] for x in ins]) for k in range(4))
+    cfg = dict(r1=2e-4, r2=5e-3, max_iter=max_iter, alpha=1.0)
+    a = run(A, B, Cc, bc, cfg, False, monkeypatch)
+    b = run(A, B, Cc, bc, cfg, True, monkeypatch)
+    assert np.array_equal(a["iters"], b["iters"]) and np.array_equal(a["err"], b["err"])
+    assert biteq(a["psi"], b["psi"]) and biteq(a["eta"], b["eta"])
+    assert a["r1"].tobytes() == b["r1"].tobytes() and a["r2"].tobytes() == b["r2"].tobytes()
+    for m in (0, 3, 6):
+        want = H.diagnose_case(A[m], B[m], Cc[m], bc[m], **cfg)["BAROTROPIC"]
+        assert int(a["iters"][m]) == want["iters"] and int(a["err"][m]) == want["err"]
+        assert biteq(a["psi"][m], want["psi"])
+        assert a["r1"][m].tobytes() == want["r1"].tobytes()
+    if max_iter == 20000:
+        assert len(set(int(v) for v in a["iters"])) > 1 and int(a["iters"].max()) < max_iter
+
+
+def test_pipelined_other_check_steps(monkeypatch):
+    """check_step that is not a multiple of the blocked launch length, tiny converge_time."""
+    nr, nz = 80, 56
+    A, B, Cc, bc = H.rich_inputs(nr, nz, seed=4)
+    prof = H.profiles(nr, nz, 0, 0, (0.0, 2.0e5, 0.0, 1.5e4))
+    sA, sB, sC = H.solver_coefficients(A, B, Cc, prof["rcuva"], prof["rho"])
+    coe = H.cal_coe(sA, sB, sC, prof["dr"], prof["dz"], nr, nz)
+    f = (-B).astype(np.float32)
+    for cs, ct, mi in ((7, 3, 5000), (25, 2, 1013), (1, 4, 40)):
+        want = H.solve(bc, coe, f, mi, 1e-6, 5e-2, 1.0, check_step=cs, converge_time=ct)
+        monkeypatch.delenv("XEE_SYNC_CHECKS", raising=False)
+        got = xee.solve_elliptic(bc, coe, f, mi, 1e-6, 5e-2, 1.0, check_step=cs, converge_time=ct)
+        assert got[1] == want[1] and got[2] == want[2], (cs, ct, mi, got[1:3], want[1:3])
+        assert biteq(got[0], want[0])
+        assert got[3].tobytes() == want[3].tobytes() and got[4].tobytes() == want[4].tobytes()

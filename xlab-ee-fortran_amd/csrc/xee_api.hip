@@ -83,6 +83,14 @@ struct xee_ensemble {
     bool base_baro = false;      // ... of the BAROTROPIC operator (BX = BY = +0: not loaded)
     UniformVals uv{};            // coefficient planes found uniform by the last assemble / coe upload
     unsigned* uv_differs = nullptr;
+    // pipelined residual checks (solve_pipelined): the check of iteration k runs on `cstream` while
+    // the sweeps of the next block already run on `stream`
+    hipStream_t cstream = nullptr;
+    hipEvent_t evE[2] = {nullptr, nullptr}, evF[2] = {nullptr, nullptr};      // sweep-side / check-side, by check parity
+    hipEvent_t evB[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};          // sweep block begin/end, by check parity
+    float* res2 = nullptr;       // second residual plane (checks alternate res / res2)
+    float* snap = nullptr;       // 2 x members planes: the iterate right after each check iteration
+    MemberState* st_host2 = nullptr;   // pinned, 2 x members
 };
 
 namespace {
@@ -322,6 +330,13 @@ int xee_ensemble_destroy(xee_ensemble_t* e)
     if (e->ex_slow) hipFree(e->ex_slow);
     if (e->uv_differs) hipFree(e->uv_differs);
     if (e->base) hipFree(e->base);
+    if (e->cstream) { hipStreamSynchronize(e->cstream); hipStreamDestroy(e->cstream); }
+    for (auto& ev : e->evE) if (ev) hipEventDestroy(ev);
+    for (auto& ev : e->evF) if (ev) hipEventDestroy(ev);
+    for (auto& pr : e->evB) for (auto& ev : pr) if (ev) hipEventDestroy(ev);
+    if (e->res2) hipFree(e->res2);
+    if (e->snap) hipFree(e->snap);
+    if (e->st_host2) hipHostFree(e->st_host2);
     if (e->st_host) hipHostFree(e->st_host);
     if (e->sums_host) hipHostFree(e->sums_host);
     for (auto& ev : e->ev) if (ev) hipEventDestroy(ev);
@@ -464,6 +479,134 @@ int xee_ensemble_assemble(xee_ensemble_t* e, int variant)
 }
 
 // solve_elliptic, xtt-lib-fortran/elliptic_tools.f90:93-265, for every member at once.
+}  // extern "C"
+
+namespace {
+
+// solve_elliptic with the residual checks PIPELINED behind the sweeps.  The check of iteration k
+// (exact norm + state machine) runs on e->cstream while the next block of sweeps already runs on
+// e->stream; a member found to have stopped at check k has, by then, been iterated further, so the
+// iterate right after every check iteration is kept in a snapshot plane (two slots, alternating)
+// and its result is taken from there.  Sweeps skip a member as soon as the state machine has
+// cleared its `active` flag on the device -- the host only needs to learn it to stop enqueuing.
+// Same values as the synchronous driver (tests run both).
+int solve_pipelined(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float alpha, int tb_T)
+{
+    const Grid& g = e->g;
+    hipStream_t s = e->stream;
+    if (!e->cstream) {
+        HIPCHK(hipStreamCreateWithFlags(&e->cstream, hipStreamNonBlocking));
+        for (auto& ev : e->evE) HIPCHK(hipEventCreate(&ev));
+        for (auto& ev : e->evF) HIPCHK(hipEventCreate(&ev));
+        for (auto& pr : e->evB) for (auto& ev : pr) HIPCHK(hipEventCreate(&ev));
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->st_host2), sizeof(MemberState) * 2 * g.members));
+    }
+    XCHK(alloc_planes(e, &e->res2));
+    XCHK(alloc_planes(e, &e->snap, 2));
+    hipStream_t c = e->cstream;
+    float* resbuf[2] = {e->res, e->res2};
+    float* snapbuf[2] = {e->snap, e->snap + (size_t)g.members * g.plane};
+
+    int cur = e->cur;
+    std::vector<int> stop_slot(g.members, -1);    // snapshot slot holding a stopped member's result
+    std::vector<char> active(g.members, 1);
+    e->timing = xee_timing_t{};
+    HIPCHK(hipEventRecord(e->ev[0], s));
+    int cnt = 0, k = 0;                           // k = number of checks enqueued
+    int final_check = -1;                         // index of a check that coincides with max_iter
+    bool all_done = (max_iter == 0), block_open = false;
+
+    // digest the result of check j (its pipeline has finished when evF[j&1] has)
+    auto digest = [&](int j) -> int {
+        HIPCHK(hipEventSynchronize(e->evF[j & 1]));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, e->evB[j & 1][0], e->evB[j & 1][1]));
+        e->timing.sweep_ms += ms;
+        const MemberState* sh = e->st_host2 + (size_t)(j & 1) * g.members;
+        all_done = true;
+        for (int m = 0; m < g.members; ++m) {
+            if (active[m] && !sh[m].active) { active[m] = 0; stop_slot[m] = j & 1; }
+            if (sh[m].active) all_done = false;
+        }
+        memcpy(e->st_host, sh, sizeof(MemberState) * g.members);
+        return XEE_OK;
+    };
+
+    while (cnt < max_iter && !all_done) {
+        const int next_check = (cnt / cs + 1) * cs;
+        const int target = next_check < max_iter ? next_check : max_iter;
+        const int n = (target - cnt) < tb_T ? (target - cnt) : tb_T;
+        cnt += n;
+        const bool check = cnt == next_check, last = cnt == max_iter;
+        const int pk = k & 1;
+        if (!block_open) { HIPCHK(hipEventRecord(e->evB[pk][0], s)); block_open = true; }
+        if (check && k >= 2) HIPCHK(hipStreamWaitEvent(s, e->evF[pk], 0));   // res/snap slot pk is free again
+        if (n == 1)
+            launch_sweep(g, e->psi[cur], e->psi[cur ^ 1], e->coe, e->f, check ? resbuf[pk] : nullptr, e->st, alpha, s);
+        else
+            launch_blocked(e, e->psi[cur], e->psi[cur ^ 1], check ? resbuf[pk] : nullptr, alpha, n);
+        cur ^= 1;
+        e->timing.sweep_launches += 1;
+        e->timing.iterations += n;
+        if (check) {
+            HIPCHK(hipEventRecord(e->evB[pk][1], s));
+            block_open = false;
+            launch_copy_active(g, e->psi[cur], snapbuf[pk], e->st, s);        // the iterate this check belongs to
+            HIPCHK(hipEventRecord(e->evE[pk], s));
+            HIPCHK(hipStreamWaitEvent(c, e->evE[pk], 0));
+            if (e->exact_serial) launch_seqsum(g, resbuf[pk], 1, g.nx - 1, 1, g.ny - 1, true, e->sums, e->st, c);
+            else launch_exact_sumsq(g, resbuf[pk], e->ex_ws, e->sums, e->ex_slow, e->st, c);
+            cp.cnt = cnt;
+            cp.is_last = last ? 1 : 0;
+            launch_conv_update(g, e->sums, e->st, cp, c);
+            HIPCHK(hipMemcpyAsync(e->st_host2 + (size_t)pk * g.members, e->st, sizeof(MemberState) * g.members,
+                                  hipMemcpyDeviceToHost, c));
+            HIPCHK(hipEventRecord(e->evF[pk], c));
+            e->timing.check_launches += 1;
+            XCHK(check_launch("sweep/check"));
+            if (last) final_check = k;
+            if (k >= 1) XCHK(digest(k - 1));                                 // one check behind the sweeps
+            ++k;
+        } else if (last) {
+            // max_iter is not a check iteration: every earlier check must be settled before :242-248 applies
+            if (k >= 1) XCHK(digest(k - 1));
+            HIPCHK(hipStreamSynchronize(c));
+            launch_finalize(g, e->st, max_iter, s);
+            HIPCHK(hipMemcpyAsync(e->st_host, e->st, sizeof(MemberState) * g.members, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            XCHK(check_launch("finalize"));
+            for (int m = 0; m < g.members; ++m) active[m] = 0;               // their result is psi[cur] itself
+            all_done = true;
+        }
+    }
+    if (k >= 1 && final_check == k - 1) XCHK(digest(k - 1));                  // the check at max_iter
+    else if (k >= 1 && !all_done) XCHK(digest(k - 1));
+    HIPCHK(hipStreamSynchronize(c));
+    HIPCHK(hipEventRecord(e->ev[1], s));
+    if (max_iter == 0) HIPCHK(hipMemcpyAsync(e->st_host, e->st, sizeof(MemberState) * g.members, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e->ev[0], e->ev[1]));
+    e->timing.solve_ms = ms;
+
+    // :259-264  results into one plane.  A member that stopped at a check has been iterated further
+    // while its check was in flight (unless that check was the very last thing enqueued): take its snapshot.
+    const bool tail_clean = (final_check >= 0 && final_check == k - 1);       // nothing ran after the last check
+    for (int m = 0; m < g.members; ++m) {
+        if (stop_slot[m] < 0) continue;                                       // ended by finalize: psi[cur] is it
+        if (tail_clean && stop_slot[m] == ((k - 1) & 1) && e->st_host[m].iters == max_iter) continue;
+        HIPCHK(hipMemcpyAsync(e->psi[cur] + (size_t)m * g.plane, snapbuf[stop_slot[m]] + (size_t)m * g.plane,
+                              sizeof(float) * g.plane, hipMemcpyDeviceToDevice, s));
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    e->cur = cur;
+    return XEE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 int xee_ensemble_solve(xee_ensemble_t* e, int max_iter, int check_step, int converge_time, int lost_rate,
                        float r1, float r2, float alpha, int flags)
 {
@@ -492,6 +635,20 @@ int xee_ensemble_solve(xee_ensemble_t* e, int max_iter, int check_step, int conv
     std::vector<int> final_buf(g.members, cur);        // plane a member's result was written to
     std::vector<char> was_active(g.members, 1);
     const int tb_T = (flags & XEE_SOLVE_SINGLE_STEP) ? 1 : e->tb_T;
+
+    // default: residual checks pipelined behind the sweeps; XEE_SYNC_CHECKS=1 (or the per-check
+    // trace, whose lines must appear in order) selects the simple synchronous driver below
+    if (!getenv("XEE_SYNC_CHECKS") && cp.debug == 0) {
+        XCHK(solve_pipelined(e, max_iter, cs, cp, alpha, tb_T));
+        for (int m = 0; m < g.members; ++m) {
+            xee_case_record_t& r = e->rec[m];
+            r.iters = e->st_host[m].iters;
+            r.err_bits = e->st_host[m].err_bits;
+            r.err_now = e->st_host[m].err_now;
+            r.ratio = e->st_host[m].ratio;
+        }
+        return XEE_OK;
+    }
 
     e->timing = xee_timing_t{};
     HIPCHK(hipEventRecord(e->ev[0], s));

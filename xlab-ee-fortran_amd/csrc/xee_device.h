@@ -100,6 +100,7 @@ void launch_finalize(const Grid& g, MemberState* st, int max_iter, hipStream_t s
 void launch_state_init(const Grid& g, MemberState* st, hipStream_t s);
 void launch_copy2(const Grid& g, const float* src, float* dst0, float* dst1, hipStream_t s);
 void launch_negate(const Grid& g, const float* src, float* dst, hipStream_t s);
+void launch_copy_active(const Grid& g, const float* src, float* dst, const MemberState* st, hipStream_t s);
 void launch_cal_eta(const Grid& g, const float* psi, float* eta, const float* ra, const float* rcuva,
                     const float* rho, const float* exner, hipStream_t s);
 void launch_cal_uw(const Grid& g, const float* psi, float* u, float* w, const float* ra,

@@ -521,6 +521,25 @@ __global__ __launch_bounds__(256) void k_copy2(size_t n4, const float4* __restri
     }
 }
 
+// snapshot of the planes of the members that are still active (pipelined checks, xee_api.hip)
+__global__ __launch_bounds__(256) void k_copy_active(size_t plane4, const float4* __restrict__ src,
+        float4* __restrict__ dst, const MemberState* __restrict__ st)
+{
+    const int m = blockIdx.y;
+    if (!st[m].active) return;
+    const float4* s = src + (size_t)m * plane4;
+    float4* d = dst + (size_t)m * plane4;
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < plane4; k += (size_t)gridDim.x * 256) d[k] = s[k];
+}
+
+void launch_copy_active(const Grid& g, const float* src, float* dst, const MemberState* st, hipStream_t s)
+{
+    const size_t plane4 = g.plane / 4;
+    const int bx = (int)((plane4 + 255) / 256 < 256 ? (plane4 + 255) / 256 : 256);
+    hipLaunchKernelGGL(k_copy_active, dim3(bx, g.members), dim3(256), 0, s, plane4,
+                       reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), st);
+}
+
 __global__ __launch_bounds__(256) void k_negate(size_t n4, const float4* __restrict__ src,
                                                 float4* __restrict__ dst)
 {
