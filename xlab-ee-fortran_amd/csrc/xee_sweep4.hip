@@ -116,9 +116,11 @@ __global__ __launch_bounds__(NW * 64) void k_sweep_tb4(Grid g, const float* __re
             const float w7 = BXm + BYm;
             const float w8 = Cm - (BXp - BXm);
             const float w9 = -(BXp + BYm);
-            c[0][r] = interior ? w1 : 0.0f; c[1][r] = interior ? w2 : 0.0f; c[2][r] = interior ? w3 : 0.0f;
-            c[3][r] = interior ? w4 : 0.0f; c[4][r] = interior ? w5 : 0.0f; c[5][r] = interior ? w6 : 0.0f;
-            c[6][r] = interior ? w7 : 0.0f; c[7][r] = interior ? w8 : 0.0f; c[8][r] = interior ? w9 : 0.0f;
+            // no masking of the weights: a non-interior point's update is discarded below (`interior ?`),
+            // and unmasked the four corner weights of the BAROTROPIC operator are compile-time +-0
+            c[0][r] = w1; c[1][r] = w2; c[2][r] = w3; c[3][r] = w4; c[4][r] = w5;
+            c[5][r] = w6; c[6][r] = w7; c[7][r] = w8; c[8][r] = w9;
+            (void)interior;
             cq_m = Cp;
             by_m = BYp;
         }
