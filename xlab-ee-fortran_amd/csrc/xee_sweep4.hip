@@ -145,6 +145,8 @@ __global__ __launch_bounds__(NW * 64) void k_sweep_tb4(Grid g, const float* __re
         lft[R + 1] = shr1(above); rgt[R + 1] = shl1(above);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
+            // (skipping the rows that can no longer reach the stored region -- the valid band shrinks by
+            // one row per step and side -- was measured: the extra branches cost more than they save)
             const float om = (r > 0) ? src[r - 1] : below;
             const float oc = src[r];
             const float on = (r + 1 < R) ? src[r + 1] : above;
