@@ -129,6 +129,29 @@ int xee_cal_wtheta(const float *w_A, const float *theta_B, float *wtheta_B, int 
  * to O points) and :523-538 (f = -1/4 sum of the 4 neighbouring B cells).  Outputs are (nr,nz). */
 int xee_rhs_thermal(const float *Q_B, const float *ra, const float *exner, float *rhs_O, int nr, int nz);
 int xee_rhs_from_B(const float *b_B, float *f_O, int nr, int nz);
+/* replaces the momentum source term RHS_rpsi_mom, src/old-diagnose/diagnose.f90:412-436:
+ * -(T(i,j)+T(i-1,j))/rcuva(i)**2 with T = d_dz_B2A(sqrt(m2)*F); m2, F on B cells (nr-1,nz-1) -> (nr,nz).
+ * Rows the reference reads from an uninitialised workspace (j = nz-1) are defined as 0 (quirk 16). */
+int xee_rhs_momentum(const float *m2_B, const float *F_B, const float *za, const float *rcuva,
+                     float *rhs_O, int nr, int nz);
+
+/* replaces the six finite-difference helpers of src/diagnose/quick-tools2.f90:1-85 (internal procedures
+ * of program main reading host-associated ra, za, rcuva -- passed explicitly here).  Shapes (n1,n2):
+ *   XEE_D_DZ_B2A     (nr-1,nz-1) -> (nr-1,nz)   rows J=2..nz-2 written, others keep the caller's bytes   :1-13
+ *   XEE_D_DZ_O2C     (nr,nz)     -> (nr,nz-1)                                                         :16-25
+ *   XEE_D_DR_B2B     (nr-1,nz-1) -> (nr-1,nz-1) one-sided at the ends                                  :27-43
+ *   XEE_D_DR_B2C     (nr-1,nz-1) -> (nr,nz-1)   columns I=2..nr-1 written                               :45-57
+ *   XEE_D_DR_O2A     (nr,nz)     -> (nr-1,nz)                                                         :59-68
+ *   XEE_D_RCUVDR_O2A (nr,nz)     -> (nr-1,nz)   d_dr_O2A / ((rcuva(I)+rcuva(I+1))/2)                   :71-85 */
+enum { XEE_D_DZ_B2A = 0, XEE_D_DZ_O2C = 1, XEE_D_DR_B2B = 2, XEE_D_DR_B2C = 3, XEE_D_DR_O2A = 4, XEE_D_RCUVDR_O2A = 5 };
+int xee_fd_stencil(int which, const float *from, float *to, const float *ra, const float *za,
+                   const float *rcuva, int nr, int nz);
+
+/* replaces cal_exchange_conversion, src/old-diagnose/diagnose.f90:1143-1174 (K9), with REAL r, dr, dz: the
+ * reference declares them `integer` (:1146), which truncates them and makes its number meaningless, so
+ * this entry is a documented fix, not a parity target.  bndconv (nr-1,2); *sum accumulated sequentially. */
+int xee_exchange_conversion(const float *rpsi, const float *rchi, const float *rhoC, const float *ra,
+                            const float *za, const float *rho, float *bndconv, float *sum, int nr, int nz);
 
 /* ---------------------------------------------------------------------------------------------
  * Tier 2 -- device-resident ensemble of independent cases on ONE GPU.

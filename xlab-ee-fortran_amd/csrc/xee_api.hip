@@ -38,6 +38,15 @@ int fail(int code, const std::string& msg)
         if (s_ != XEE_OK) return s_;     \
     } while (0)
 
+}  // namespace
+
+// for the other translation units of the library (xee_stencils.hip): record a failure text
+namespace xee {
+int record_failure(int code, const char* msg) { return fail(code, msg ? msg : ""); }
+}
+
+namespace {
+
 int require_device()
 {
     int n = 0;

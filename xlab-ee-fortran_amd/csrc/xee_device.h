@@ -116,6 +116,7 @@ void launch_rhs_thermal(const Grid& g, const float* Q, const float* ra, const fl
 void launch_rhs_from_B(const Grid& g, const float* b, float* f, hipStream_t s);
 void launch_coe_aos_to_soa(const Grid& g, const float* aos /* (9,nx,ny) packed */, float* coe, hipStream_t s);
 void launch_coe_soa_to_aos(const Grid& g, const float* coe, float* aos, hipStream_t s);
+int    record_failure(int code, const char* msg);   // sets xee_last_error() of this thread, returns code
 size_t seqsum_lds_bytes(const Grid& g, int nrows);
 int    sweep_kernel_setup();   // one-time function attributes; returns hipError_t as int
 

@@ -83,6 +83,9 @@ def lib():
     L.xee_cal_wtheta.argtypes = [_f32p] * 3 + [C.c_int, C.c_int]
     L.xee_rhs_thermal.argtypes = [_f32p] * 4 + [C.c_int, C.c_int]
     L.xee_rhs_from_B.argtypes = [_f32p] * 2 + [C.c_int, C.c_int]
+    L.xee_rhs_momentum.argtypes = [_f32p] * 5 + [C.c_int, C.c_int]
+    L.xee_fd_stencil.argtypes = [C.c_int] + [_f32p] * 5 + [C.c_int, C.c_int]
+    L.xee_exchange_conversion.argtypes = [_f32p] * 7 + [_pf, C.c_int, C.c_int]
     vp = C.c_void_p
     L.xee_ensemble_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int]
     L.xee_ensemble_destroy.argtypes = [vp]
@@ -233,6 +236,37 @@ def rhs_from_B(b_B):
     out = np.zeros((nzm + 1, nrm + 1), np.float32)
     _chk(lib().xee_rhs_from_B(_a(b_B), out, nrm + 1, nzm + 1))
     return out
+
+
+FD_STENCILS = {"d_dz_B2A": 0, "d_dz_O2C": 1, "d_dr_B2B": 2, "d_dr_B2C": 3, "d_dr_O2A": 4, "d_rcuvdr_O2A": 5}
+
+
+def fd_stencil(name, from_dat, prof, to_dat=None):
+    """quick-tools2.f90:1-85.  `to_dat` seeds the entries the reference leaves untouched (default zeros)."""
+    which = FD_STENCILS[name]
+    n2f, n1f = from_dat.shape
+    nr, nz = (n1f + 1, n2f + 1) if name in ("d_dz_B2A", "d_dr_B2B", "d_dr_B2C") else (n1f, n2f)
+    shape = {"d_dz_B2A": (nz, nr - 1), "d_dz_O2C": (nz - 1, nr), "d_dr_B2B": (nz - 1, nr - 1),
+             "d_dr_B2C": (nz - 1, nr), "d_dr_O2A": (nz, nr - 1), "d_rcuvdr_O2A": (nz, nr - 1)}[name]
+    out = np.zeros(shape, np.float32) if to_dat is None else _a(to_dat).copy()
+    _chk(lib().xee_fd_stencil(which, _a(from_dat), out, prof["ra"], prof["za"], prof["rcuva"], nr, nz))
+    return out
+
+
+def rhs_momentum(m2_B, F_B, prof):
+    nzm, nrm = m2_B.shape
+    out = np.zeros((nzm + 1, nrm + 1), np.float32)
+    _chk(lib().xee_rhs_momentum(_a(m2_B), _a(F_B), prof["za"], prof["rcuva"], out, nrm + 1, nzm + 1))
+    return out
+
+
+def exchange_conversion(rpsi, rchi, rhoC, prof):
+    nz, nr = rpsi.shape
+    bnd = np.zeros((2, nr - 1), np.float32)
+    s = C.c_float()
+    _chk(lib().xee_exchange_conversion(_a(rpsi), _a(rchi), _a(rhoC), prof["ra"], prof["za"], prof["rho"], bnd,
+                                       C.byref(s), nr, nz))
+    return bnd, np.float32(s.value)
 
 
 # ---- Tier 2: device-resident ensemble ---------------------------------------------------------
