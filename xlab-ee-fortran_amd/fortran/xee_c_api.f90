@@ -126,6 +126,33 @@ interface
         type(xee_case_record), intent(out) :: rec(*)
         integer(c_int) :: st
     end function
+
+    ! host-array stencils of the two driver programs (quick-tools2.f90:1-85; old-diagnose/diagnose.f90:412-436,
+    ! :1143-1174); which = 0..5 in the order d_dz_B2A, d_dz_O2C, d_dr_B2B, d_dr_B2C, d_dr_O2A, d_rcuvdr_O2A
+    function xee_fd_stencil(which, from_dat, to_dat, ra, za, rcuva, nr, nz) bind(C, name="xee_fd_stencil") result(st)
+        import :: c_int, c_float
+        integer(c_int), value :: which, nr, nz
+        real(c_float), intent(in) :: from_dat(*), ra(*), za(*), rcuva(*)
+        real(c_float), intent(inout) :: to_dat(*)
+        integer(c_int) :: st
+    end function
+
+    function xee_rhs_momentum(m2_B, F_B, za, rcuva, rhs_O, nr, nz) bind(C, name="xee_rhs_momentum") result(st)
+        import :: c_int, c_float
+        real(c_float), intent(in) :: m2_B(*), F_B(*), za(*), rcuva(*)
+        real(c_float), intent(out) :: rhs_O(*)
+        integer(c_int), value :: nr, nz
+        integer(c_int) :: st
+    end function
+
+    function xee_exchange_conversion(rpsi, rchi, rhoC, ra, za, rho, bndconv, total, nr, nz)   &
+        &                            bind(C, name="xee_exchange_conversion") result(st)
+        import :: c_int, c_float
+        real(c_float), intent(in) :: rpsi(*), rchi(*), rhoC(*), ra(*), za(*), rho(*)
+        real(c_float), intent(out) :: bndconv(*), total
+        integer(c_int), value :: nr, nz
+        integer(c_int) :: st
+    end function
 end interface
 
 contains
