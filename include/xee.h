@@ -251,6 +251,12 @@ int xee_ensemble_timing(xee_ensemble_t *ens, xee_timing_t *out);
  * (0 = streaming, 1 = temporally blocked) between HIP events; does not touch the records */
 int xee_ensemble_time_sweeps(xee_ensemble_t *ens, int iters, int variant, float alpha,
                              double *elapsed_ms, int64_t *launches);
+/* validation aid for the blocked sweep's strength-reduced update (csrc/xee_sweepq.hip): draws
+ * blocks*256*per_thread operand pairs (a, d), |d| in [2^d_exp_lo, 2^(d_exp_hi+1)), a over the range the
+ * kernel admits for that d, and counts the pairs whose hoisted-reciprocal quotient differs from the IEEE
+ * division a/d (the quotient of elliptic_tools.f90:238).  Must report 0. */
+int xee_quotient_selfcheck(int device, uint64_t seed, int blocks, int per_thread, int d_exp_lo, int d_exp_hi,
+                           uint64_t *mismatches, float *first_bad /* 2: a, d of one failing pair */);
 
 #ifdef __cplusplus
 }

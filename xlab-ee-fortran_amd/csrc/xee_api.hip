@@ -183,8 +183,11 @@ int detect_uniform_planes(xee_ensemble* e)
 void launch_blocked(xee_ensemble* e, const float* psi_in, float* psi_out, float* res, float alpha, int T)
 {
     const bool no_base4 = getenv("XEE_NO_BASE4") != nullptr;   // A/B switch for tests and probes
-    if (e->have_base && !no_base4)
-        launch_sweep_tb4(e->g, psi_in, psi_out, e->base, e->f, res, e->st, alpha, T, e->base_baro, e->stream);
+    if (e->have_base && !no_base4) {
+        static const bool no_fastq = getenv("XEE_NO_FASTQ") != nullptr;   // A/B switch: the plain IEEE-division kernel
+        if (no_fastq) launch_sweep_tb4(e->g, psi_in, psi_out, e->base, e->f, res, e->st, alpha, T, e->base_baro, e->stream);
+        else launch_sweep_q(e->g, psi_in, psi_out, e->base, e->f, res, e->st, alpha, T, e->base_baro, e->stream);
+    }
     else
         launch_sweep_tb(e->g, psi_in, psi_out, e->coe, e->f, res, e->st, alpha, T, e->uv, e->stream);
 }
@@ -859,6 +862,36 @@ int xee_ensemble_timing(xee_ensemble_t* e, xee_timing_t* out)
 {
     if (!e || !out) return fail(XEE_ERR_INVALID_ARGUMENT, "null argument");
     *out = e->timing;
+    return XEE_OK;
+}
+
+int xee_quotient_selfcheck(int device, uint64_t seed, int blocks, int per_thread, int d_exp_lo, int d_exp_hi,
+                           uint64_t* mismatches, float* first_bad)
+{
+    if (!mismatches || blocks < 1 || per_thread < 1 || d_exp_lo > d_exp_hi || d_exp_lo < -120 || d_exp_hi > 119)
+        return fail(XEE_ERR_INVALID_ARGUMENT, "quotient_selfcheck: bad arguments");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) return fail(XEE_ERR_NO_DEVICE, "no HIP device");
+    HIPCHK(hipSetDevice(device < 0 ? 0 : device));
+    unsigned long long* d_cnt = nullptr;
+    float* d_bad = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&d_cnt), 2 * sizeof(unsigned long long)));
+    hipError_t he = hipMalloc(reinterpret_cast<void**>(&d_bad), 2 * sizeof(float));
+    unsigned long long h_cnt[2] = {0, 0};
+    float h_bad[2] = {0.f, 0.f};
+    if (he == hipSuccess) he = hipMemset(d_cnt, 0, 2 * sizeof(unsigned long long));
+    if (he == hipSuccess) he = hipMemset(d_bad, 0, 2 * sizeof(float));
+    if (he == hipSuccess) {
+        launch_quotient_check(seed, blocks, per_thread, d_exp_lo, d_exp_hi, d_cnt, d_bad, nullptr);
+        he = hipMemcpy(h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost);
+    }
+    if (he == hipSuccess) he = hipMemcpy(h_bad, d_bad, sizeof(h_bad), hipMemcpyDeviceToHost);
+    if (he == hipSuccess) he = hipGetLastError();
+    hipFree(d_cnt);
+    if (d_bad) hipFree(d_bad);
+    if (he != hipSuccess) return fail(XEE_ERR_HIP, std::string("quotient_selfcheck: ") + hipGetErrorString(he));
+    *mismatches = h_cnt[0];
+    if (first_bad) { first_bad[0] = h_bad[0]; first_bad[1] = h_bad[1]; }
     return XEE_OK;
 }
 

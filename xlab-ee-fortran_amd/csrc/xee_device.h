@@ -86,6 +86,13 @@ void launch_base_planes(const Grid& g, const float* sA, const float* sB /* nullp
                         float* base, float dx, float dy, hipStream_t s);
 void launch_sweep_tb4(const Grid& g, const float* psi_in, float* psi_out, const float* base, const float* f,
                       float* res, const MemberState* st, float alpha, int T, bool barotropic, hipStream_t s);
+// the same, with the loop-invariant half of the update's division hoisted and a validated optimistic body
+// per tile (xee_sweepq.hip); bit-identical to launch_sweep_tb4
+void launch_sweep_q(const Grid& g, const float* psi_in, float* psi_out, const float* base, const float* f,
+                    float* res, const MemberState* st, float alpha, int T, bool barotropic, hipStream_t s);
+void launch_quotient_check(unsigned long long seed, int blocks, int per_thread, int d_exp_lo, int d_exp_hi,
+                           unsigned long long* mismatches /* device, 2 words */, float* first_bad /* device, 2 */,
+                           hipStream_t s);
 int  tb_max_T();
 // opt-in, non-parity: one 4-colour SOR iteration in place; residual plane of the current iterate
 void launch_sor_iteration(const Grid& g, float* psi, const float* coe, const float* f, const MemberState* st,

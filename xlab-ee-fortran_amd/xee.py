@@ -107,6 +107,8 @@ def lib():
     L.xee_ensemble_records.argtypes = [vp, C.c_void_p]
     L.xee_ensemble_timing.argtypes = [vp, C.POINTER(Timing)]
     L.xee_ensemble_time_sweeps.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.xee_quotient_selfcheck.argtypes = [C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
     _lib = L
     return L
 
@@ -270,6 +272,14 @@ def exchange_conversion(rpsi, rchi, rhoC, prof):
 
 
 # ---- Tier 2: device-resident ensemble ---------------------------------------------------------
+
+def quotient_selfcheck(seed, blocks, per_thread, d_exp_lo, d_exp_hi, device=-1):
+    """Count the operand pairs on which the blocked sweep's hoisted-reciprocal quotient differs from the IEEE
+    division (csrc/xee_sweepq.hip); returns (mismatches, (a, d) of one failing pair)."""
+    bad, first = C.c_uint64(), (C.c_float * 2)()
+    _chk(lib().xee_quotient_selfcheck(device, seed, blocks, per_thread, d_exp_lo, d_exp_hi, C.byref(bad), first))
+    return bad.value, (first[0], first[1])
+
 
 class Ensemble:
     """N independent cases of one grid on one GPU (xee_ensemble_* of include/xee.h)."""
