@@ -50,7 +50,7 @@ def member_fields(nr, nz, m):
     return one, B.astype(np.float32), one, np.zeros((nz, nr), np.float32), Q.astype(np.float32)
 
 
-def traffic_per_launch(kernel, nr, nz, members, T):
+def traffic_per_launch(kernel, nr, nz, members, T, operator="BAROTROPIC"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/traffic.json, corrections documented in profiles/r01/pmc/README.md); None unless an
     entry was measured for exactly this workload."""
@@ -58,7 +58,7 @@ def traffic_per_launch(kernel, nr, nz, members, T):
         ent = json.loads((ROOT / "profiles" / "traffic.json").read_text()).get(kernel)
     except (OSError, ValueError):
         return None
-    if ent and (ent["nr"], ent["nz"], ent["members"], ent["T"]) == (nr, nz, members, T):
+    if ent and (ent["nr"], ent["nz"], ent["members"], ent["T"], ent.get("operator", "BAROTROPIC")) == (nr, nz, members, T, operator):
         return ent["bytes_per_launch"]
     return None
 
@@ -180,7 +180,8 @@ def main():
         alg_bytes = BYTES_PER_POINT_ITER * interior * M * iters        # this rank, all timed steps
         achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
         tb_T = int(os.environ.get("XEE_TB_T", "6"))
-        kernel = ("k_sweep_tb" if os.environ.get("XEE_NO_BASE4") else "k_sweep_tb4") if tb_T > 1 else "k_sweep_stream"
+        kernel = ("k_sweep_tb" if os.environ.get("XEE_NO_BASE4") else
+                  "k_sweep_tb4" if os.environ.get("XEE_NO_FASTQ") else "k_sweep_q") if tb_T > 1 else "k_sweep_stream"
         out = {
             "metric": "diagnosed cases/s (1024x512 r-z grid, SOR to 1e-8)",
             "value": cases / dt, "unit": "cases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -198,7 +199,8 @@ def main():
             "point_updates_per_s": world * M * iters * interior / dt,
             "all_cases_ran_to_max_iter": bool(len(rec) == world * M and np.all(rec["iters"] == args.max_iter)),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_per_launch(kernel, nr, nz, M, tb_T),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_per_launch(kernel, nr, nz, M, tb_T,
+                                                                                "BAROCLINIC" if args.workload == "baroclinic" else "BAROTROPIC"),
                          "kernel": f"{kernel} (damped-Jacobi sweep, {tb_T} iteration(s) per launch; temporal blocking "
                                    "makes the effective rate exceed the HBM peak: traffic << algorithmic bytes)",
                          "algorithmic_bytes_per_launch": alg_bytes / max(launches, 1),

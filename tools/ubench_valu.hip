@@ -24,8 +24,10 @@ static const char* kind_name[K_N] = {"v_fma_f32", "v_mul_f32", "v_add_f32", "v_p
     "IEEE a/b (compiler sequence)", "a*y, fma, fma (3-op quotient)"};
 
 template <int KIND>
-__global__ __launch_bounds__(256) void k_bench(float* out, float seed)
+__global__ __launch_bounds__(256) void k_bench(float* out, float seed, unsigned long long* ticks)
 {
+    unsigned long long tk0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tk0) : : "memory");
     __shared__ float lds[4096];
     float a[16];
     float2v p[16];
@@ -130,6 +132,9 @@ __global__ __launch_bounds__(256) void k_bench(float* out, float seed)
             }
         }
     }
+    unsigned long long tk1;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tk1) : : "memory");
+    if (threadIdx.x == 0) ticks[blockIdx.x] = tk1 - tk0;
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) s += a[i] + p[i].x + p[i].y;
@@ -139,22 +144,29 @@ __global__ __launch_bounds__(256) void k_bench(float* out, float seed)
 template <int KIND>
 static void run(float* d_out, int n_cu, double ghz)
 {
+    static unsigned long long* d_ticks = nullptr;
+    if (!d_ticks) CK(hipMalloc(&d_ticks, 4096 * sizeof(unsigned long long)));
+    std::vector<unsigned long long> h_ticks(4096);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     printf("%-36s", kind_name[KIND]);
     for (int wps : {1, 2, 4}) {
         const int grid = n_cu * wps;              // 256 threads = 4 waves = one wave per SIMD per workgroup
-        hipLaunchKernelGGL(k_bench<KIND>, dim3(grid), dim3(256), 0, 0, d_out, 1.0f);
+        hipLaunchKernelGGL(k_bench<KIND>, dim3(grid), dim3(256), 0, 0, d_out, 1.0f, d_ticks);
         CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL(k_bench<KIND>, dim3(grid), dim3(256), 0, 0, d_out, 1.0f);
+        hipLaunchKernelGGL(k_bench<KIND>, dim3(grid), dim3(256), 0, 0, d_out, 1.0f, d_ticks);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         float ms = 0;
         CK(hipEventElapsedTime(&ms, e0, e1));
         const double cyc = ms * 1e-3 * ghz * 1e9 / ((double)ITERS * 16 * wps);
-        printf("  %dw/SIMD: %6.2f cyc", wps, cyc);
+        CK(hipMemcpy(h_ticks.data(), d_ticks, grid * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        double tsum = 0;
+        for (int i = 0; i < grid; ++i) tsum += (double)h_ticks[i];
+        // ticks per wave-instruction per SIMD: a workgroup's lifetime / (its instructions x co-resident waves per SIMD)
+        printf("  %dw/SIMD: %6.2f cyc %6.2f tick", wps, cyc, tsum / grid / ((double)ITERS * 16 * wps));
     }
     printf("\n");
     fflush(stdout);

@@ -74,12 +74,24 @@ struct TileGeom {
     int lane, w, x0, y0, gx, gy0;
     bool col_in, col_int, vx;
     size_t mo, ks;
+    unsigned long long* stamps;     // developer timeline (tools/probe_q.hip) or nullptr
 };
+
+// s_memtime at a phase boundary of the tile (STAMP builds only: tools/probe_q.hip)
+template <bool STAMP>
+__device__ __forceinline__ void stamp(const TileGeom& tg, int slot)
+{
+    if constexpr (STAMP) {
+        unsigned long long t;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+        if (threadIdx.x == 0) tg.stamps[slot] = t;
+    }
+}
 
 // One tile, T steps.  FAST: the optimistic body; returns whether the WHOLE workgroup validated, and only
 // then stores.  !FAST: the exact body (the arithmetic of k_sweep_tb4); always stores.
-template <int NW, int R, bool WRITE_R, bool BARO, bool FAST>
-__device__ __forceinline__ bool sweep_tile(const Grid& g, const TileGeom& tg, float (*edge)[2][NW][64],
+template <int NW, int R, bool WRITE_R, bool BARO, bool FAST, bool STAMP = false>
+__device__ __forceinline__ bool sweep_tile(const Grid& g, const TileGeom& tg, float (*edge)[2][NW][64], int* vote,
         const float* __restrict__ psi_in, float* __restrict__ psi_out, const float* __restrict__ base,
         const float* __restrict__ f, float* __restrict__ res, float alpha, int T)
 {
@@ -123,6 +135,7 @@ __device__ __forceinline__ bool sweep_tile(const Grid& g, const TileGeom& tg, fl
             rcq[r] = (cqm + o)[cx];
             if constexpr (!BARO) { rbx[r] = (bxm + o)[cx]; rby[r] = (bym + o)[cx]; }
         }
+        stamp<STAMP>(tg, 1);                                // loads issued
         const float y_idle = alpha > 0.0f ? -0.0f : 0.0f;   // (alpha*1) * y_idle = -0
         const int gyb = gy0 - 1;
         const bool inb = tg.col_in && gyb >= 0 && gyb < g.ny;
@@ -175,18 +188,22 @@ __device__ __forceinline__ bool sweep_tile(const Grid& g, const TileGeom& tg, fl
         }
     }
 
+    stamp<STAMP>(tg, 2);                                  // weights built
     float amax = 0.0f, amin = __builtin_inff();           // running extremes of |alpha * R| (FAST)
     float q[R], rl[(FAST && WRITE_R) ? R : 1];
+    // One Jacobi step src -> dst.  The edge rows of src are already in LDS (written by the tail of the previous
+    // step, or before the loop); after the barrier the neighbours' rows are requested and, in the star body, the
+    // rows that do not need them (1..R-2) are computed first, so the LDS round trip hides behind the step's work.
+    // (Measured alternatives, tools/probe_q.hip: the barrier costs about as much as a step's arithmetic -- 9.6k
+    // ticks per 6 steps with it, 5.7k without -- but per-neighbour flags in LDS instead are worse still, 13.9k:
+    // waves that spin on a flag take issue slots from the wave they wait for.)
     auto step = [&](const float (&src)[R], float (&dst)[R], int t) {
         const int par = t & 1;
-        edge[par][0][w][lane] = src[R - 1];
-        edge[par][1][w][lane] = src[0];
         __syncthreads();
         const float below = (w > 0) ? edge[par][0][w - 1][lane] : 0.0f;
         const float above = (w < NW - 1) ? edge[par][1][w + 1][lane] : 0.0f;
         if constexpr (STAR) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
+            auto row = [&](int r) {
                 const float om = (r > 0) ? src[r - 1] : below;
                 const float oc = src[r];
                 const float on = (r + 1 < R) ? src[r + 1] : above;
@@ -202,7 +219,11 @@ __device__ __forceinline__ bool sweep_tile(const Grid& g, const TileGeom& tg, fl
                 amax = __builtin_fmaxf(amax, __builtin_fabsf(a));
                 amin = __builtin_fminf(amin, __builtin_fabsf(a));
                 if (WRITE_R && t == T - 1) rl[WRITE_R ? r : 0] = Rv;
-            }
+            };
+#pragma unroll
+            for (int r = 1; r < R - 1; ++r) row(r);
+            row(0);
+            row(R - 1);
         } else {
             // the i-1 / i+1 views of rows -1..R of the old iterate, one DPP move each
             float lft[R + 2], rgt[R + 2];
@@ -244,12 +265,19 @@ __device__ __forceinline__ bool sweep_tile(const Grid& g, const TileGeom& tg, fl
                 }
             }
         }
+        if (t + 1 < T) {                                      // the next step's exchange
+            edge[par ^ 1][0][w][lane] = dst[R - 1];
+            edge[par ^ 1][1][w][lane] = dst[0];
+        }
     };
+    edge[0][0][w][lane] = p[R - 1];
+    edge[0][1][w][lane] = p[0];
     for (int t = 0; t < T; t += 2) {
         step(p, q, t);
         if (t + 1 < T) step(q, p, t + 1);
     }
     const bool in_q = (T & 1) != 0;                       // odd T: the last step wrote q
+    stamp<STAMP>(tg, 3);                                  // T steps done
 
     if constexpr (FAST) {
         bool ok = dmin >= 0x1p-120f && dmax <= 0x1p120f;
@@ -258,8 +286,14 @@ __device__ __forceinline__ bool sweep_tile(const Grid& g, const TileGeom& tg, fl
         ok = ok && amin >= a_lo && amax <= a_hi;
 #pragma unroll
         for (int r = 0; r < R; ++r) ok = ok && __builtin_fabsf(in_q ? q[r] : p[r]) <= FLT_MAX;   // false for NaN too
-        if (!__syncthreads_and(ok ? 1 : 0)) return false;
+        // one-barrier vote (__syncthreads_and takes three): a flag per wave, then every wave looks at all of them
+        const bool wave_bad = __builtin_amdgcn_ballot_w64(!ok) != 0;
+        if (lane == 0) vote[w] = wave_bad ? 1 : 0;
+        __syncthreads();
+        const int v = vote[lane % NW];
+        if (__builtin_amdgcn_ballot_w64(v != 0) != 0) return false;
     }
+    stamp<STAMP>(tg, 4);                                  // validated
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int ly = w * R + r;
@@ -272,17 +306,22 @@ __device__ __forceinline__ bool sweep_tile(const Grid& g, const TileGeom& tg, fl
             if constexpr (FAST && WRITE_R) res[o] = rl[r];
         }
     }
+    stamp<STAMP>(tg, 5);                                  // stores issued
     return true;
 }
 
 }  // namespace
 
-template <int NW, int R, bool WRITE_R, bool BARO>
-__global__ __launch_bounds__(NW * 64) void k_sweep_q(Grid g, const float* __restrict__ psi_in,
+// (HIP's second launch bound is waves per SIMD: 4 keeps the 8x8 BAROTROPIC kernels at 128 VGPRs, i.e. two
+// workgroups per CU, also for the residual-writing variant)
+template <int NW, int R, bool WRITE_R, bool BARO, bool STAMP = false>
+__global__ __launch_bounds__(NW * 64, (BARO && NW * R <= 64) ? 4 : 1) void k_sweep_q(Grid g, const float* __restrict__ psi_in,
         float* __restrict__ psi_out, const float* __restrict__ base, const float* __restrict__ f,
-        float* __restrict__ res, const MemberState* __restrict__ st, float alpha, int T, int exact_only)
+        float* __restrict__ res, const MemberState* __restrict__ st, float alpha, int T, int exact_only,
+        unsigned long long* __restrict__ stamps)
 {
     __shared__ float edge[2][2][NW][64];
+    __shared__ int vote[NW];
     const int m = blockIdx.z;
     if (st && !st[m].active) return;                      // workgroup-uniform
     constexpr int H = NW * R;
@@ -298,8 +337,20 @@ __global__ __launch_bounds__(NW * 64) void k_sweep_q(Grid g, const float* __rest
     tg.vx = (tg.lane >= T || tg.x0 <= 0) && (tg.lane < 64 - T || tg.x0 + 63 >= g.nx - 1);
     tg.mo = (size_t)m * g.plane;
     tg.ks = (size_t)g.members * g.plane;
-    if (!exact_only && sweep_tile<NW, R, WRITE_R, BARO, true>(g, tg, edge, psi_in, psi_out, base, f, res, alpha, T)) return;
-    sweep_tile<NW, R, WRITE_R, BARO, false>(g, tg, edge, psi_in, psi_out, base, f, res, alpha, T);
+    tg.stamps = nullptr;
+    if constexpr (STAMP) {
+        tg.stamps = stamps + 32 * ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+        stamp<STAMP>(tg, 0);                              // workgroup started
+        if (threadIdx.x == 0)                             // HW_ID (cu/sh/se in bits 8..15) and XCC_ID
+            tg.stamps[7] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |
+                           ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);
+    }
+    if (!exact_only && sweep_tile<NW, R, WRITE_R, BARO, true, STAMP>(g, tg, edge, vote, psi_in, psi_out, base, f, res, alpha, T)) {
+        stamp<STAMP>(tg, 6);
+        return;
+    }
+    sweep_tile<NW, R, WRITE_R, BARO, false, STAMP>(g, tg, edge, vote, psi_in, psi_out, base, f, res, alpha, T);
+    stamp<STAMP>(tg, 6);
 }
 
 // validation kernel for the quotient identity: n pairs per thread drawn from a counter-based generator
@@ -357,9 +408,9 @@ static void launch_q_cfg(const Grid& g, const float* psi_in, float* psi_out, con
     constexpr int H = NW * R;
     dim3 grid((g.nx - 1 + (64 - 2 * T) - 1) / (64 - 2 * T), (g.ny - 1 + (H - 2 * T) - 1) / (H - 2 * T), g.members);
     if (res)
-        hipLaunchKernelGGL((k_sweep_q<NW, R, true, BARO>), grid, dim3(NW * 64), 0, s, g, psi_in, psi_out, base, f, res, st, alpha, T, exact_only);
+        hipLaunchKernelGGL((k_sweep_q<NW, R, true, BARO>), grid, dim3(NW * 64), 0, s, g, psi_in, psi_out, base, f, res, st, alpha, T, exact_only, (unsigned long long*)nullptr);
     else
-        hipLaunchKernelGGL((k_sweep_q<NW, R, false, BARO>), grid, dim3(NW * 64), 0, s, g, psi_in, psi_out, base, f, res, st, alpha, T, exact_only);
+        hipLaunchKernelGGL((k_sweep_q<NW, R, false, BARO>), grid, dim3(NW * 64), 0, s, g, psi_in, psi_out, base, f, res, st, alpha, T, exact_only, (unsigned long long*)nullptr);
 }
 
 void launch_sweep_q(const Grid& g, const float* psi_in, float* psi_out, const float* base, const float* f,
@@ -381,9 +432,12 @@ void launch_sweep_q(const Grid& g, const float* psi_in, float* psi_out, const fl
         Q_CASE(4, 16)
         Q_CASE(16, 8)
         Q_CASE(16, 4)
+        Q_CASE(8, 6)
         default:
             if (barotropic) launch_q_cfg<8, 8, true>(g, psi_in, psi_out, base, f, res, st, alpha, T, exact_only, s);
-            else launch_q_cfg<8, 8, false>(g, psi_in, psi_out, base, f, res, st, alpha, T, exact_only, s);
+            // (the nine-weight body needs 156 VGPRs at eight rows per lane -- one workgroup per CU; at six it fits
+            // two: 8.9 against 7.1 cases/s on the baroclinic bench workload)
+            else launch_q_cfg<8, 6, false>(g, psi_in, psi_out, base, f, res, st, alpha, T, exact_only, s);
     }
 #undef Q_CASE
 }
