@@ -90,3 +90,11 @@ def test_fast_body_matches_exact_kernel(kind):
     exact = _digest(kind, {"XEE_NO_FASTQ": "1"})
     forced = _digest(kind, {"XEE_Q_EXACT_ONLY": "1"})
     assert fast == exact == forced
+
+
+@pytest.mark.parametrize("rows", ["4", "6", "8"])
+@pytest.mark.parametrize("kind", ["tropic", "tropic-zero", "tropic-explode", "tropic-tiny"])
+def test_slim_star_kernel_matches_exact_kernel(kind, rows):
+    """The opt-in slim form of the star body (weights shared between neighbours, f and y1 in LDS, psi updated in
+    place, its own exact redo): same bits as the plain IEEE-division kernel."""
+    assert _digest(kind, {"XEE_SLIM_ROWS": rows}) == _digest(kind, {"XEE_NO_FASTQ": "1"})
