@@ -94,7 +94,8 @@ __device__ __forceinline__ void stamp(const TileGeom& tg, int slot)
 template <int NW, int R, bool WRITE_R, bool BARO, bool FAST, bool STAMP = false>
 __device__ __forceinline__ bool sweep_tile(const Grid& g, const TileGeom& tg, float (*edge)[2][NW][64], int* vote,
         const float* __restrict__ psi_in, float* __restrict__ psi_out, const float* __restrict__ base,
-        const float* __restrict__ f, float* __restrict__ res, float alpha, int T)
+        const float* __restrict__ f, float* __restrict__ res, float alpha, int T,
+        const MemberState* __restrict__ member = nullptr /* if given: return at once when it has stopped */)
 {
     constexpr int H = NW * R;
     constexpr bool STAR = FAST && BARO;
@@ -137,6 +138,9 @@ __device__ __forceinline__ bool sweep_tile(const Grid& g, const TileGeom& tg, fl
             if constexpr (!BARO) { rbx[r] = (bxm + o)[cx]; rby[r] = (bym + o)[cx]; }
         }
         stamp<STAMP>(tg, 1);                                // loads issued
+        // (only now the member's `active` flag is looked at: testing it first would put a scalar-memory round
+        // trip in front of the tile's loads; for a stopped member the loads above are harmless)
+        if (member && !member->active) return true;         // workgroup-uniform
         const float y_idle = alpha > 0.0f ? -0.0f : 0.0f;   // (alpha*1) * y_idle = -0
         const int gyb = gy0 - 1;
         const bool inb = tg.col_in && gyb >= 0 && gyb < g.ny;
@@ -324,7 +328,7 @@ __global__ __launch_bounds__(NW * 64, (BARO && NW * R <= 64) ? 4 : 1) void k_swe
     __shared__ float edge[2][2][NW][64];
     __shared__ int vote[NW];
     const int m = blockIdx.z;
-    if (st && !st[m].active) return;                      // workgroup-uniform
+    const MemberState* member = st ? st + m : nullptr;
     constexpr int H = NW * R;
     TileGeom tg;
     tg.lane = threadIdx.x & 63;
@@ -346,11 +350,11 @@ __global__ __launch_bounds__(NW * 64, (BARO && NW * R <= 64) ? 4 : 1) void k_swe
             tg.stamps[7] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |
                            ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);
     }
-    if (!exact_only && sweep_tile<NW, R, WRITE_R, BARO, true, STAMP>(g, tg, edge, vote, psi_in, psi_out, base, f, res, alpha, T)) {
+    if (!exact_only && sweep_tile<NW, R, WRITE_R, BARO, true, STAMP>(g, tg, edge, vote, psi_in, psi_out, base, f, res, alpha, T, member)) {
         stamp<STAMP>(tg, 6);
         return;
     }
-    sweep_tile<NW, R, WRITE_R, BARO, false, STAMP>(g, tg, edge, vote, psi_in, psi_out, base, f, res, alpha, T);
+    sweep_tile<NW, R, WRITE_R, BARO, false, STAMP>(g, tg, edge, vote, psi_in, psi_out, base, f, res, alpha, T, member);
     stamp<STAMP>(tg, 6);
 }
 
