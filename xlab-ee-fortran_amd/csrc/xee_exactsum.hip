@@ -29,6 +29,8 @@
 //   Typically ~25 of the 16,352 chunks of a 1024x512 plane take the slow path.
 #include "xee_device.h"
 
+#include <type_traits>
+
 #pragma clang fp contract(off)
 
 namespace xee {
@@ -37,6 +39,8 @@ namespace {
 
 constexpr int SEG = EXACT_SEG;
 constexpr int MAXREP = 48;      // columns whose chunk summaries are staged in LDS for the walk
+constexpr int MAXT = 64;        // chunks whose 32 terms are staged in LDS as well (the ones known to need genuine adds)
+constexpr int MAXSEG = 64;      // segments per column the term map is sized for (2048 rows)
 
 __device__ __forceinline__ unsigned f2u(float x) { return __builtin_bit_cast(unsigned, x); }
 __device__ __forceinline__ float u2f(unsigned x) { return __builtin_bit_cast(float, x); }
@@ -212,7 +216,10 @@ __global__ __launch_bounds__(64) void k_ex_walk(Grid g, const float* __restrict_
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int rep_of[MAXREP];       // staged column ids
-    __shared__ int nrep_s;
+    __shared__ int nrep_s, nterm_s;
+    __shared__ float terms[MAXT][SEG];   // squared residuals of the chunks staged for the slow path
+    __shared__ short term_of[MAXREP * MAXSEG];   // staged chunk (rep slot, segment) -> row of `terms`, or -1
+    __shared__ short term_src[MAXT];     // ... and back
     const int m = blockIdx.x;
     if (st && !st[m].active) return;
     const int lane = threadIdx.x;
@@ -222,7 +229,7 @@ __global__ __launch_bounds__(64) void k_ex_walk(Grid g, const float* __restrict_
     ExactSum* rep_l = cols_l + (cols_in_lds ? ncol : 0);                          // [MAXREP][nseg]
 
     // stage the column summaries, and the chunk summaries of the columns that will need a descent
-    if (lane == 0) nrep_s = 0;
+    if (lane == 0) { nrep_s = 0; nterm_s = 0; }
     __syncthreads();
     // (loads are issued in batches of 8 per lane so that their latencies overlap)
     if (cols_in_lds) {
@@ -251,7 +258,36 @@ __global__ __launch_bounds__(64) void k_ex_walk(Grid g, const float* __restrict_
             if (e < nstage) tmp[u] = chunk[((size_t)m * ncol + rep_of[e / nseg]) * nseg + e % nseg];
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int e = base + u * 64 + lane; if (e < nstage) rep_l[e] = tmp[u]; }
+        for (int u = 0; u < 8; ++u) {
+            const int e = base + u * 64 + lane;
+            if (e < nstage) {
+                rep_l[e] = tmp[u];
+                // a chunk without a valid summary will get its genuine additions in the walk: stage its terms too,
+                // so that the walk does not wait for global memory at every such chunk
+                if (nseg <= MAXSEG) {
+                    int slot = -1;
+                    if (!tmp[u].valid) { slot = atomicAdd(&nterm_s, 1); if (slot >= MAXT) slot = -1; else term_src[slot] = (short)e; }
+                    term_of[e] = (short)slot;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int nterm = (nseg <= MAXSEG) ? min(nterm_s, MAXT) : 0;
+    for (int base = 0; base < nterm * SEG; base += 64 * 8) {
+        float tmp[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * 64 + lane;
+            tmp[u] = 0.0f;
+            if (idx < nterm * SEG) {
+                const int e = term_src[idx / SEG], r = idx % SEG;
+                const ChunkAddr a = chunk_addr(g, Rm, rep_of[e / nseg], e % nseg, nrows);
+                if (r < a.n) { const float x = a.p[(size_t)r * g.pitch]; tmp[u] = x * x; }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int idx = base + u * 64 + lane; if (idx < nterm * SEG) terms[idx / SEG][idx % SEG] = tmp[u]; }
     }
     __syncthreads();
     const ExactSum* cols = cols_in_lds ? cols_l : cols_g;
@@ -262,24 +298,46 @@ __global__ __launch_bounds__(64) void k_ex_walk(Grid g, const float* __restrict_
     // lane l holds summary number l of a window; after the inclusive scan it holds the run [0..l].
     // Runs that are valid for the current binade and keep the sum inside it form a prefix (K only
     // grows); the longest is applied.  Returns how many summaries were consumed.
+    // The scan runs on DPP moves (row_shr 1, 2, 4, 8 inside each row of 16 lanes, then row_bcast:15 and
+    // row_bcast:31 across rows) -- register-to-register, a few cycles each -- instead of ds_bpermute shuffles,
+    // which go through the LDS crossbar: this kernel is one wave per member and a chain of ~90 dependent scans,
+    // so the scan's latency is its run time.  compose() is associative but not commutative: every step puts the
+    // EARLIER run on the left.
     auto scan_take = [&](ExactSum me) -> int {
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            // two shuffles per step: ke (24 bits) | eu+149 (8 bits), ko (24 bits) | valid
-            const unsigned w0 = __shfl_up(me.ke | ((unsigned)(me.eu + 149) << 24), off, 64);
-            const unsigned w1 = __shfl_up(me.ko | ((unsigned)me.valid << 24), off, 64);
-            ExactSum a;
-            a.ke = w0 & 0xffffffu; a.eu = (int)(w0 >> 24) - 149;
-            a.ko = w1 & 0xffffffu; a.valid = (int)(w1 >> 24);
-            if (lane >= off) me = compose(a, me);
-        }
-        const unsigned nb = bits + ((bits & 1u) ? me.ko : me.ke);
+        // Only summaries counted for the binade the sum is in NOW can be applied, and only as a prefix: find the
+        // first one that cannot, then scan the bare ulp counts (two words, three operations per composition)
+        // of all 64 lanes -- what lies at or beyond that lane cannot influence the lanes before it.
+        const int eu_now = ulp_exp(bits);
+        const unsigned long long good = __ballot(me.valid && me.eu == eu_now);
+        const int first_bad = (good == ~0ull) ? 64 : __builtin_ctzll(~good);
+        if (first_bad == 0) return 0;
+        unsigned ke = me.ke, ko = me.ko;
+        auto stepd = [&](auto ctrl_tag, auto rmask_tag, bool has) {
+            constexpr int CTRL = decltype(ctrl_tag)::value, RMASK = decltype(rmask_tag)::value;
+            const unsigned a_ke = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ke, CTRL, RMASK, 0xf, false);
+            const unsigned a_ko = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ko, CTRL, RMASK, 0xf, false);
+            // compose(a, me): the earlier run a on the left
+            const unsigned nke = a_ke + ((a_ke & 1u) ? ko : ke);
+            const unsigned nko = a_ko + ((a_ko & 1u) ? ke : ko);
+            if (has) { ke = nke; ko = nko; }
+        };
+        using std::integral_constant;
+        const int rl = lane & 15;
+        stepd(integral_constant<int, 0x111>{}, integral_constant<int, 0xf>{}, rl >= 1);       // row_shr:1
+        stepd(integral_constant<int, 0x112>{}, integral_constant<int, 0xf>{}, rl >= 2);       // row_shr:2
+        stepd(integral_constant<int, 0x114>{}, integral_constant<int, 0xf>{}, rl >= 4);       // row_shr:4
+        stepd(integral_constant<int, 0x118>{}, integral_constant<int, 0xf>{}, rl >= 8);       // row_shr:8
+        stepd(integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{}, (lane & 16) != 0);   // row_bcast:15 -> rows 1, 3
+        stepd(integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{}, lane >= 32);         // row_bcast:31 -> rows 2, 3
+        const unsigned nb = bits + ((bits & 1u) ? ko : ke);
         const unsigned e0 = bits >> 23, e1 = nb >> 23;
-        // K ulps keep the sum in its binade iff the exponent field (0 and 1 merged) is unchanged
-        const bool fits = me.valid && me.eu == ulp_exp(bits) && (e0 > 1u ? e0 : 1u) == (e1 > 1u ? e1 : 1u) && e1 < 255u;
+        // K ulps keep the sum in its binade iff the exponent field (0 and 1 merged) is unchanged; the counts are
+        // non-decreasing along the lanes, so the runs that fit form a prefix as well
+        const bool fits = lane < first_bad && ke < (1u << 24) && ko < (1u << 24) &&
+                          (e0 > 1u ? e0 : 1u) == (e1 > 1u ? e1 : 1u) && e1 < 255u;
         const unsigned long long mask = __ballot(fits);
         const int n = (mask == ~0ull) ? 64 : __builtin_ctzll(~mask);
-        if (n > 0) bits = __shfl(nb, n - 1, 64);
+        if (n > 0) bits = (unsigned)__builtin_amdgcn_readlane((int)nb, __builtin_amdgcn_readfirstlane(n - 1));
         return n;
     };
     const ExactSum none = {0u, 0u, 0, 0};
@@ -290,7 +348,11 @@ __global__ __launch_bounds__(64) void k_ex_walk(Grid g, const float* __restrict_
         if (n == 64 || col >= ncol) continue;
         // column `col` is the first of the window that does not fit as a whole: the same game over its chunks
         const ExactSum* ch = chunk + ((size_t)m * ncol + col) * nseg;
-        for (int k = 0; k < nrep; ++k) if (rep_of[k] == col) ch = rep_l + (size_t)k * nseg;   // staged copy
+        int krep = -1;                                        // staged copy?  (one compare per lane instead of a search)
+        {
+            const unsigned long long hit = __ballot(lane < nrep && rep_of[lane < MAXREP ? lane : 0] == col);
+            if (hit) { krep = __builtin_ctzll(hit); ch = rep_l + (size_t)krep * nseg; }
+        }
         for (int seg = 0; seg < nseg;) {
             const int eu_now = ulp_exp(bits);
             ExactSum me = none;
@@ -310,7 +372,9 @@ __global__ __launch_bounds__(64) void k_ex_walk(Grid g, const float* __restrict_
             // genuine sequential fp32 additions -- lanes fetch, the sum runs in reference order
             const ChunkAddr a = chunk_addr(g, Rm, col, seg, nrows);
             float t = 0.0f;
-            if (lane < a.n) { const float x = a.p[(size_t)lane * g.pitch]; t = x * x; }
+            const int ts = (krep >= 0 && nseg <= MAXSEG) ? (int)term_of[krep * nseg + seg] : -1;
+            if (ts >= 0) { if (lane < SEG) t = terms[ts][lane]; }          // (rows beyond a.n were staged as 0 and are not added)
+            else if (lane < a.n) { const float x = a.p[(size_t)lane * g.pitch]; t = x * x; }
             float sacc = u2f(bits);
             const int tb = (int)f2u(t);
 #pragma unroll
@@ -341,7 +405,7 @@ size_t exact_ws_bytes(const Grid& g)
 int exact_kernel_setup()
 {
     return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ex_walk),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
 }
 
 void launch_exact_sumsq(const Grid& g, const float* R, void* workspace, float* out_sums, int* slow_chunks,
@@ -366,7 +430,7 @@ void launch_exact_sumsq(const Grid& g, const float* R, void* workspace, float* o
     // LDS: all column summaries + the chunk summaries of up to MAXREP columns, when that fits
     size_t lds = ((size_t)ncol + (size_t)MAXREP * nseg) * sizeof(ExactSum);
     int cols_in_lds = 1;
-    if (lds > 150 * 1024) { lds = 0; cols_in_lds = 0; }
+    if (lds > 128 * 1024) { lds = 0; cols_in_lds = 0; }         // (+ ~15 KiB of static LDS in the walk)
     hipLaunchKernelGGL(k_ex_walk, dim3(g.members), dim3(64), lds, s, g, R, ncol, nseg, nrows, chunk, colsum, out_sums,
                        slow_chunks, st, cols_in_lds);
 }
