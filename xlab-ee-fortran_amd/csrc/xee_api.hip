@@ -85,6 +85,7 @@ struct xee_ensemble {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int tb_T = 6;   // iterations per temporally blocked launch (XEE_TB_T overrides)
     void* ex_ws = nullptr;       // workspace of the parallel order-exact residual norm
+    void* sx_ws = nullptr;       // ... and of the order-exact sum of signed terms (EE integrals), allocated on first use
     int* ex_slow = nullptr;      // per member: chunks the last check summed term by term
     bool exact_serial = false;   // XEE_EXACT_SUM=serial: single-lane reference-order walk instead
     float* base = nullptr;       // the operator's four generating planes AP, CQ, BX, BY (xee_sweep4.hip)
@@ -339,6 +340,7 @@ int xee_ensemble_destroy(xee_ensemble_t* e)
         if (p) hipFree(p);
     if (e->st) hipFree(e->st);
     if (e->ex_ws) hipFree(e->ex_ws);
+    if (e->sx_ws) hipFree(e->sx_ws);
     if (e->ex_slow) hipFree(e->ex_slow);
     if (e->uv_differs) hipFree(e->uv_differs);
     if (e->base) hipFree(e->base);
@@ -824,6 +826,24 @@ int xee_ensemble_cal_uw(xee_ensemble_t* e)
     return check_launch("cal_uw");
 }
 
+namespace {
+// e->sums[m] = sequential fp32 sum of e->terms over [0,nx-1) x [0,ny-1), reference order (old-diagnose/diagnose.f90:1029-1048)
+int ee_sum(xee_ensemble* e, hipStream_t s)
+{
+    const Grid& g = e->g;
+    if (e->exact_serial) {
+        launch_seqsum(g, e->terms, 0, g.nx - 1, 0, g.ny - 1, false, e->sums, nullptr, s);
+        return XEE_OK;
+    }
+    if (!e->sx_ws && hipMalloc(&e->sx_ws, exact_signed_ws_bytes(g)) != hipSuccess) {
+        e->sx_ws = nullptr;
+        return fail(XEE_ERR_ALLOC, "hipMalloc signed exact-sum workspace");
+    }
+    launch_exact_sum_signed(g, e->terms, 0, g.nx - 1, 0, g.ny - 1, e->sx_ws, e->sums, nullptr, s);
+    return XEE_OK;
+}
+}  // namespace
+
 int xee_ensemble_ee_scalars(xee_ensemble_t* e)
 {
     XCHK(use(e));
@@ -834,12 +854,12 @@ int xee_ensemble_ee_scalars(xee_ensemble_t* e)
     hipStream_t s = e->stream;
     std::vector<float> sq(g.members);
     launch_terms_weight(g, e->Q, e->terms, e->ra, e->za, e->rcuva, e->rho, s);
-    launch_seqsum(g, e->terms, 0, g.nx - 1, 0, g.ny - 1, false, e->sums, nullptr, s);
+    XCHK(ee_sum(e, s));
     HIPCHK(hipMemcpyAsync(e->sums_host, e->sums, sizeof(float) * g.members, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     for (int m = 0; m < g.members; ++m) sq[m] = e->sums_host[m];
     launch_terms_Qeta(g, e->Q, e->eta, e->terms, e->ra, e->za, e->rcuva, e->rho, s);
-    launch_seqsum(g, e->terms, 0, g.nx - 1, 0, g.ny - 1, false, e->sums, nullptr, s);
+    XCHK(ee_sum(e, s));
     HIPCHK(hipMemcpyAsync(e->sums_host, e->sums, sizeof(float) * g.members, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     XCHK(check_launch("ee_scalars"));
@@ -1124,7 +1144,7 @@ static int integrate_common(const float* wgt, const float* eta, const float* ra,
     } else {
         launch_terms_weight(e->g, e->Q, e->terms, e->ra, e->za, e->rcuva, e->rho, e->stream);
     }
-    launch_seqsum(e->g, e->terms, 0, nr - 1, 0, nz - 1, false, e->sums, nullptr, e->stream);
+    XCHK(ee_sum(e, e->stream));
     XCHK(check_launch("integrate"));
     HIPCHK(hipMemcpyAsync(e->sums_host, e->sums, sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));

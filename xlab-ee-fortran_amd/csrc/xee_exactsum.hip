@@ -435,4 +435,258 @@ void launch_exact_sumsq(const Grid& g, const float* R, void* workspace, float* o
                        slow_chunks, st, cols_in_lds);
 }
 
+// =============================================================================================
+// The same idea for terms of EITHER SIGN (the EE integrals: sum Q, sum Q*eta of
+// old-diagnose/diagnose.f90:1029-1092 are sequential fp32 sums, i outer / j inner, over (nr-1) x (nz-1)
+// terms of either sign; a single lane needs 3 ms at 1024x512 and 44 ms at 4096x2048).
+//
+// Write the running sum as a SIGNED integer V of ulps, |V| in [2^23, 2^24): while it stays in its binade
+// and keeps its sign, fl(s + t) = rne_even(V + t/u) * u for a term of either sign, so a chunk still maps
+// the parity of the incoming V to the signed ulp count it adds -- (K_even, K_odd) -- but the counts are
+// no longer monotone: the summary also carries the extremes (kmin, kmax) over all its prefixes, taken
+// over both parities (conservative), and a run may be applied only if V + kmin .. V + kmax stays inside
+// [2^23 + 1, 2^24 - 1] in magnitude (at |V| = 2^23 exactly the spacing below is u/2 and the model stops
+// holding for a term that reduces |s|).  compose() of the counts is associative as before; the extremes
+// compose conservatively, which is all validity needs.  Everything that does not fit -- the start from 0,
+// sign changes, binade crossings, cancellation down into lower binades -- is added term by term.
+// =============================================================================================
+namespace {
+
+struct SSum {
+    int ke, ko;        // signed ulps added for an even / odd incoming V
+    int kmin, kmax;    // extremes of the prefixes' counts (both parities), including the empty prefix (0)
+    int eu;            // log2(ulp) of the binade the counts are valid for
+    int valid;
+};
+
+constexpr int KLIM = 1 << 24;
+
+__device__ __forceinline__ SSum schunk_summary(const ChunkAddr& a, int pitch, int eu)
+{
+    int ke = 0, ko = 0, kmin = 0, kmax = 0;
+    bool ok = true;
+    for (int r = 0; r < a.n; ++r) {
+        const unsigned tb = f2u(a.p[(size_t)r * pitch]);
+        const unsigned Et = (tb >> 23) & 0xffu;
+        const unsigned fr = tb & 0x7fffffu;
+        if (Et == 255u) { ok = false; break; }               // Inf / NaN term: genuine adds only
+        const unsigned Mt = Et ? (fr | 0x800000u) : fr;
+        if (Mt == 0u) continue;                              // +-0
+        const int shift = eu - ((int)(Et ? Et : 1u) - 150);
+        if (shift <= 0) { ok = false; break; }               // |term| >= 2^23 ulps: leaves the binade
+        if (shift >= 25) continue;                           // below half an ulp: absorbed (either sign)
+        const unsigned q = Mt >> shift;
+        const unsigned rem = Mt & ((1u << shift) - 1u);
+        const unsigned half = 1u << (shift - 1);
+        // V +- q and its neighbour one further out: above half the farther one, a tie goes to the even one
+        const unsigned pe = (unsigned)ke & 1u, po = ((unsigned)ko & 1u) ^ 1u;          // parity of V so far
+        const int de = (int)(q + ((rem > half) || (rem == half && ((pe ^ q) & 1u))));
+        const int dd = (int)(q + ((rem > half) || (rem == half && ((po ^ q) & 1u))));
+        if (tb >> 31) { ke -= de; ko -= dd; } else { ke += de; ko += dd; }
+        kmin = min(kmin, min(ke, ko));
+        kmax = max(kmax, max(ke, ko));
+        if (kmin < -KLIM || kmax > KLIM) { ok = false; break; }
+    }
+    SSum out;
+    out.eu = eu;
+    out.valid = ok ? 1 : 0;
+    out.ke = ok ? ke : 0; out.ko = ok ? ko : 0; out.kmin = ok ? kmin : 0; out.kmax = ok ? kmax : 0;
+    return out;
+}
+
+__device__ __forceinline__ SSum scompose(const SSum& a, const SSum& b)
+{
+    SSum o;
+    o.ke = a.ke + ((a.ke & 1) ? b.ko : b.ke);
+    o.ko = a.ko + ((a.ko & 1) ? b.ke : b.ko);
+    o.kmin = min(a.kmin, min(a.ke, a.ko) + b.kmin);
+    o.kmax = max(a.kmax, max(a.ke, a.ko) + b.kmax);
+    o.eu = a.eu;
+    o.valid = (a.valid && b.valid && a.eu == b.eu && o.kmin >= -KLIM && o.kmax <= KLIM) ? 1 : 0;
+    if (!o.valid) { o.ke = 0; o.ko = 0; o.kmin = 0; o.kmax = 0; }
+    return o;
+}
+
+// chunk (column, segment) of a rectangle that starts at (i0, j0): terms T(i0+col, j0 + seg*SEG + r)
+__device__ __forceinline__ ChunkAddr schunk_addr(const Grid& g, const float* Tm, int i0, int j0, int col, int seg, int nrows)
+{
+    ChunkAddr a;
+    const int r0 = seg * SEG;
+    a.n = min(SEG, nrows - r0);
+    a.p = Tm + (size_t)(j0 + r0) * g.pitch + (i0 + col);
+    return a;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void k_sx_chunk_sums(Grid g, const float* __restrict__ T, int i0, int j0, int ncol, int nseg,
+        int nrows, double* __restrict__ sigma, const MemberState* __restrict__ st)
+{
+    const int m = blockIdx.z;
+    if (st && !st[m].active) return;
+    const int col = blockIdx.x * 64 + threadIdx.x;
+    const int seg = blockIdx.y * 4 + threadIdx.y;
+    if (col >= ncol || seg >= nseg) return;
+    const ChunkAddr a = schunk_addr(g, T + (size_t)m * g.plane, i0, j0, col, seg, nrows);
+    double acc = 0.0;
+    for (int r = 0; r < a.n; ++r) acc += (double)a.p[(size_t)r * g.pitch];
+    sigma[(size_t)m * ncol * nseg + (size_t)col * nseg + seg] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_sx_chunk_summaries(Grid g, const float* __restrict__ T, int i0, int j0, int ncol,
+        int nseg, int nrows, const double* __restrict__ prefix, const double* __restrict__ coloff,
+        SSum* __restrict__ chunk, const MemberState* __restrict__ st)
+{
+    const int m = blockIdx.z;
+    if (st && !st[m].active) return;
+    const int col = blockIdx.x * 64 + threadIdx.x;
+    const int seg = blockIdx.y * 4 + threadIdx.y;
+    if (col >= ncol || seg >= nseg) return;
+    const size_t c = (size_t)m * ncol * nseg + (size_t)col * nseg + seg;
+    const double P = fabs(coloff[(size_t)m * ncol + col] + prefix[c]);
+    SSum out;
+    if (!(P >= 1.2e-38) || !(P < 3.0e38)) {                  // zero / subnormal / NaN / Inf / overflowing prediction
+        out.ke = 0; out.ko = 0; out.kmin = 0; out.kmax = 0; out.eu = -100000; out.valid = 0;
+    } else {
+        out = schunk_summary(schunk_addr(g, T + (size_t)m * g.plane, i0, j0, col, seg, nrows), g.pitch, ulp_exp(f2u((float)P)));
+    }
+    chunk[c] = out;
+}
+
+__global__ __launch_bounds__(256) void k_sx_col_summaries(int ncol, int nseg, const SSum* __restrict__ chunk,
+        SSum* __restrict__ colsum, const MemberState* __restrict__ st)
+{
+    const int m = blockIdx.y;
+    if (st && !st[m].active) return;
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= ncol) return;
+    const SSum* cs = chunk + ((size_t)m * ncol + col) * nseg;
+    SSum out = cs[0];
+    for (int k = 1; k < nseg && out.valid; ++k) out = scompose(out, cs[k]);
+    colsum[(size_t)m * ncol + col] = out;
+}
+
+// the walk: one wave per member
+__global__ __launch_bounds__(64) void k_sx_walk(Grid g, const float* __restrict__ T, int i0, int j0, int ncol, int nseg, int nrows,
+        const SSum* __restrict__ chunk, const SSum* __restrict__ colsum, float* __restrict__ out,
+        const MemberState* __restrict__ st)
+{
+    const int m = blockIdx.x;
+    if (st && !st[m].active) return;
+    const int lane = threadIdx.x;
+    const float* Tm = T + (size_t)m * g.plane;
+    const SSum* cols = colsum + (size_t)m * ncol;
+    unsigned bits = 0u;                                       // the sum starts at +0
+
+    auto scan_take = [&](SSum me) -> int {
+        const unsigned E = (bits >> 23) & 0xffu;
+        if (E == 0u || E == 255u) return 0;                   // zero / subnormal / non-finite sum: term by term
+        const int eu_now = (int)E - 150;
+        const unsigned long long good = __ballot(me.valid && me.eu == eu_now);
+        const int first_bad = (good == ~0ull) ? 64 : __builtin_ctzll(~good);
+        if (first_bad == 0) return 0;
+        int ke = me.ke, ko = me.ko, kmin = me.kmin, kmax = me.kmax;
+        auto stepd = [&](auto ctrl_tag, auto rmask_tag, bool has) {
+            constexpr int CTRL = decltype(ctrl_tag)::value, RMASK = decltype(rmask_tag)::value;
+            const int a_ke = __builtin_amdgcn_update_dpp(0, ke, CTRL, RMASK, 0xf, false);
+            const int a_ko = __builtin_amdgcn_update_dpp(0, ko, CTRL, RMASK, 0xf, false);
+            const int a_mn = __builtin_amdgcn_update_dpp(0, kmin, CTRL, RMASK, 0xf, false);
+            const int a_mx = __builtin_amdgcn_update_dpp(0, kmax, CTRL, RMASK, 0xf, false);
+            // scompose(a, me): the earlier run a on the left (valid runs only: |counts| <= 64 * 2^24)
+            const int nke = a_ke + ((a_ke & 1) ? ko : ke);
+            const int nko = a_ko + ((a_ko & 1) ? ke : ko);
+            const int nmn = min(a_mn, min(a_ke, a_ko) + kmin);
+            const int nmx = max(a_mx, max(a_ke, a_ko) + kmax);
+            if (has) { ke = nke; ko = nko; kmin = nmn; kmax = nmx; }
+        };
+        using std::integral_constant;
+        const int rl = lane & 15;
+        stepd(integral_constant<int, 0x111>{}, integral_constant<int, 0xf>{}, rl >= 1);
+        stepd(integral_constant<int, 0x112>{}, integral_constant<int, 0xf>{}, rl >= 2);
+        stepd(integral_constant<int, 0x114>{}, integral_constant<int, 0xf>{}, rl >= 4);
+        stepd(integral_constant<int, 0x118>{}, integral_constant<int, 0xf>{}, rl >= 8);
+        stepd(integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{}, (lane & 16) != 0);
+        stepd(integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{}, lane >= 32);
+        // apply to the magnitude M of the sum (V = +-M; the parity of V is the parity of M)
+        const int M = (int)((bits & 0x7fffffu) | 0x800000u);
+        const bool neg = (bits >> 31) != 0u;
+        const int K = (M & 1) ? ko : ke;
+        const int newM = neg ? M - K : M + K;
+        const int lo = neg ? M - kmax : M + kmin;
+        const int hi = neg ? M - kmin : M + kmax;
+        const bool fits = lane < first_bad && lo >= 0x800001 && hi <= 0xffffff;      // (kmin falls, kmax grows along the lanes)
+        const unsigned long long mask = __ballot(fits);
+        const int n = (mask == ~0ull) ? 64 : __builtin_ctzll(~mask);
+        const unsigned nb = (bits & 0xff800000u) | ((unsigned)newM & 0x7fffffu);
+        if (n > 0) bits = (unsigned)__builtin_amdgcn_readlane((int)nb, __builtin_amdgcn_readfirstlane(n - 1));
+        return n;
+    };
+    const SSum none = {0, 0, 0, 0, 0, 0};
+
+    for (int col = 0; col < ncol;) {
+        const int n = scan_take(col + lane < ncol ? cols[col + lane] : none);
+        col += n;
+        if (n == 64 || col >= ncol) continue;
+        const SSum* ch = chunk + ((size_t)m * ncol + col) * nseg;
+        for (int seg = 0; seg < nseg;) {
+            const unsigned E = (bits >> 23) & 0xffu;
+            const int eu_now = (int)E - 150;
+            SSum me = none;
+            if (seg + lane < nseg) me = ch[seg + lane];
+            // (see k_ex_walk) a first chunk counted for another binade: the prediction was off, recount the window
+            const bool stale = (seg + lane < nseg) && me.eu != eu_now;
+            if (E != 0u && E != 255u && __shfl((int)stale, 0, 64)) {
+                if (stale) me = schunk_summary(schunk_addr(g, Tm, i0, j0, col, seg + lane, nrows), g.pitch, eu_now);
+            } else if (stale) {
+                me = none;
+            }
+            seg += scan_take(me);
+            if (seg >= nseg) break;
+            // chunk `seg` does not fit: its genuine fp32 additions, in reference order
+            const ChunkAddr a = schunk_addr(g, Tm, i0, j0, col, seg, nrows);
+            float t = 0.0f;
+            if (lane < a.n) t = a.p[(size_t)lane * g.pitch];
+            float sacc = u2f(bits);
+            const int tb = (int)f2u(t);
+#pragma unroll
+            for (int r = 0; r < SEG; ++r)
+                if (r < a.n) sacc = sacc + u2f((unsigned)__builtin_amdgcn_readlane(tb, r));
+            bits = f2u(sacc);
+            ++seg;
+        }
+        ++col;
+    }
+    if (lane == 0) out[m] = u2f(bits);
+}
+
+size_t exact_signed_ws_bytes(const Grid& g)
+{
+    const int ncol = g.nx, nrows = g.ny;                      // any sub-rectangle of a plane
+    const int nseg = (nrows + SEG - 1) / SEG;
+    const size_t nchunk = (size_t)ncol * nseg;
+    return (size_t)g.members * (nchunk * (sizeof(double) + sizeof(SSum)) + (size_t)ncol * (2 * sizeof(double) + sizeof(SSum))) + 256;
+}
+
+void launch_exact_sum_signed(const Grid& g, const float* T, int i0, int i1, int j0, int j1, void* workspace,
+                             float* out_sums, const MemberState* st, hipStream_t s)
+{
+    const int ncol = i1 - i0, nrows = j1 - j0;
+    const int nseg = (nrows + SEG - 1) / SEG;
+    const size_t nchunk = (size_t)ncol * nseg;
+    char* w = static_cast<char*>(workspace);
+    double* sigma = reinterpret_cast<double*>(w);               w += (size_t)g.members * nchunk * sizeof(double);
+    double* coltot = reinterpret_cast<double*>(w);              w += (size_t)g.members * ncol * sizeof(double);
+    double* coloff = reinterpret_cast<double*>(w);              w += (size_t)g.members * ncol * sizeof(double);
+    SSum* chunk = reinterpret_cast<SSum*>(w);                   w += (size_t)g.members * nchunk * sizeof(SSum);
+    SSum* colsum = reinterpret_cast<SSum*>(w);
+    const dim3 gc((ncol + 63) / 64, (nseg + 3) / 4, g.members), bc(64, 4, 1);
+    const dim3 gcol((ncol + 255) / 256, g.members);
+    hipLaunchKernelGGL(k_sx_chunk_sums, gc, bc, 0, s, g, T, i0, j0, ncol, nseg, nrows, sigma, st);
+    hipLaunchKernelGGL(k_ex_col_prefix, gcol, dim3(256), 0, s, ncol, nseg, sigma, coltot, st);
+    hipLaunchKernelGGL(k_ex_scan_cols, dim3(g.members), dim3(1024), 0, s, ncol, coltot, coloff, st);
+    hipLaunchKernelGGL(k_sx_chunk_summaries, gc, bc, 0, s, g, T, i0, j0, ncol, nseg, nrows, sigma, coloff, chunk, st);
+    hipLaunchKernelGGL(k_sx_col_summaries, gcol, dim3(256), 0, s, ncol, nseg, chunk, colsum, st);
+    hipLaunchKernelGGL(k_sx_walk, dim3(g.members), dim3(64), 0, s, g, T, i0, j0, ncol, nseg, nrows, chunk, colsum, out_sums, st);
+}
+
 }  // namespace xee
