@@ -9,6 +9,51 @@
 #include <map>
 #include <vector>
 
+// experiment: the same tile body in a loop (grid = resident workgroups), with an optional start delay for half of them
+template <int NW, int R, bool STAMP>
+__global__ __launch_bounds__(NW * 64, 4) void k_probe_loop(xee::Grid g, const float* __restrict__ psi_in, float* __restrict__ psi_out,
+        const float* __restrict__ base, const float* __restrict__ f, float alpha, int T, int ntx, int nty, int stagger, int swizzle,
+        unsigned long long* __restrict__ stamps)
+{
+    using namespace xee;
+    __shared__ float edge[2][2][NW][64];
+    __shared__ int vote[2][NW];
+    constexpr int H = NW * R;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tiles_per_member = ntx * nty;
+    const int ntiles = tiles_per_member * g.members;
+    const int nb = gridDim.x;
+    const int b = (swizzle && nb % 8 == 0) ? (int)(blockIdx.x % 8) * (nb / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    if (stagger > 0 && ((int)blockIdx.x / 8) % 2 == 1)       // every other workgroup of an XCD
+        for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    for (int tile = b, k = 0; tile < ntiles; tile += nb, ++k) {
+        const int m = tile / tiles_per_member, rem = tile % tiles_per_member;
+        TileGeom tg;
+        tg.lane = lane; tg.w = w;
+        tg.x0 = (rem % ntx) * (64 - 2 * T) - T;
+        tg.y0 = (rem / ntx) * (H - 2 * T) - T;
+        tg.gx = tg.x0 + lane; tg.gy0 = tg.y0 + w * R;
+        tg.col_in = tg.gx >= 0 && tg.gx < g.nx;
+        tg.col_int = tg.gx >= 1 && tg.gx <= g.nx - 2;
+        tg.vx = (lane >= T || tg.x0 <= 0) && (lane < 64 - T || tg.x0 + 63 >= g.nx - 1);
+        tg.mo = (size_t)m * g.plane;
+        tg.ks = (size_t)g.members * g.plane;
+        tg.stamps = STAMP ? stamps + 32 * (size_t)tile : nullptr;
+        if constexpr (STAMP) {
+            stamp<STAMP>(tg, 0);
+            if (threadIdx.x == 0)
+                tg.stamps[7] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |
+                               ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);
+        }
+        if (!sweep_tile<NW, R, false, true, true, STAMP>(g, tg, edge, vote[k & 1], psi_in, psi_out, base, f, nullptr, alpha, T)) {
+            sweep_tile<NW, R, false, true, false, STAMP>(g, tg, edge, vote[k & 1], psi_in, psi_out, base, f, nullptr, alpha, T);
+            __syncthreads();
+        }
+        stamp<STAMP>(tg, 6);
+    }
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 int main(int argc, char** argv)
@@ -16,6 +61,10 @@ int main(int argc, char** argv)
     using namespace xee;
     const int T = argc > 1 ? atoi(argv[1]) : 6;
     const int members = argc > 2 ? atoi(argv[2]) : 32;
+    const int loop_mode = argc > 3 ? atoi(argv[3]) : 0;      // 1: tile-loop kernel
+    const int stagger = argc > 4 ? atoi(argv[4]) : 0;
+    const int swizzle = argc > 5 ? atoi(argv[5]) : 1;
+    const int per_cu = argc > 6 ? atoi(argv[6]) : 2;
     Grid g{};
     g.nx = 1024; g.ny = 512; g.pitch = 1024; g.plane = (size_t)g.pitch * g.ny; g.members = members;
     const size_t n = g.plane * members;
@@ -49,6 +98,10 @@ int main(int argc, char** argv)
     for (int rep = 0; rep < 3; ++rep) {
         CK(hipEventRecord(e0));
         for (int k = 0; k < 10; ++k)
+            if (loop_mode)
+                hipLaunchKernelGGL((k_probe_loop<NW, R, false>), dim3(256 * per_cu), dim3(NW * 64), 0, 0, g, (k & 1) ? psi1 : psi0, (k & 1) ? psi0 : psi1,
+                                   base, f, 1.0f, T, (int)grid.x, (int)grid.y, stagger, swizzle, (unsigned long long*)nullptr);
+            else
             hipLaunchKernelGGL((k_sweep_q<NW, R, false, true, false>), grid, dim3(NW * 64), 0, 0, g, (k & 1) ? psi1 : psi0, (k & 1) ? psi0 : psi1,
                                base, f, (float*)nullptr, (const MemberState*)nullptr, 1.0f, T, 0, (unsigned long long*)nullptr);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
@@ -56,6 +109,10 @@ int main(int argc, char** argv)
     }
     for (int rep = 0; rep < 3; ++rep) {
         CK(hipEventRecord(e0));
+        if (loop_mode)
+            hipLaunchKernelGGL((k_probe_loop<NW, R, true>), dim3(256 * per_cu), dim3(NW * 64), 0, 0, g, psi0, psi1, base, f, 1.0f, T,
+                               (int)grid.x, (int)grid.y, stagger, swizzle, stamps);
+        else
         hipLaunchKernelGGL((k_sweep_q<NW, R, false, true, true>), grid, dim3(NW * 64), 0, 0, g, psi0, psi1, base, f, (float*)nullptr,
                            (const MemberState*)nullptr, 1.0f, T, 0, stamps);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
