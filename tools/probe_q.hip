@@ -54,6 +54,62 @@ __global__ __launch_bounds__(NW * 64, 4) void k_probe_loop(xee::Grid g, const fl
     }
 }
 
+// experiment: the slim star body (103 VGPRs) in a tile loop
+template <int NW, int R>
+__global__ __launch_bounds__(NW * 64, 4) void k_probe_sloop(xee::Grid g, const float* __restrict__ psi_in, float* __restrict__ psi_out,
+        const float* __restrict__ base, const float* __restrict__ f, float alpha, int T, int ntx, int nty, int swizzle)
+{
+    using namespace xee;
+    __shared__ xee_f2 fy[NW][R][64];
+    __shared__ float edge[2][2][NW][64];
+    __shared__ int vote[2][NW];
+    constexpr int H = NW * R;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tiles_per_member = ntx * nty;
+    const int ntiles = tiles_per_member * g.members;
+    const int nb = gridDim.x;
+    const int b = (swizzle && nb % 8 == 0) ? (int)(blockIdx.x % 8) * (nb / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    for (int tile = b, k = 0; tile < ntiles; tile += nb, ++k) {
+        const int m = tile / tiles_per_member, rem = tile % tiles_per_member;
+        TileGeom tg;
+        tg.lane = lane; tg.w = w;
+        tg.x0 = (rem % ntx) * (64 - 2 * T) - T;
+        tg.y0 = (rem / ntx) * (H - 2 * T) - T;
+        tg.gx = tg.x0 + lane; tg.gy0 = tg.y0 + w * R;
+        tg.col_in = tg.gx >= 0 && tg.gx < g.nx;
+        tg.col_int = tg.gx >= 1 && tg.gx <= g.nx - 2;
+        tg.vx = (lane >= T || tg.x0 <= 0) && (lane < 64 - T || tg.x0 + 63 >= g.nx - 1);
+        tg.mo = (size_t)m * g.plane;
+        tg.ks = (size_t)g.members * g.plane;
+        tg.stamps = nullptr;
+        slim_tile<NW, R, false>(g, tg, fy, edge, vote[k & 1], psi_in, psi_out, base, f, nullptr, alpha, T, nullptr);
+    }
+}
+
+template <int NW, int R>
+__global__ __launch_bounds__(NW * 64, 4) void k_probe_s1(xee::Grid g, const float* __restrict__ psi_in, float* __restrict__ psi_out,
+        const float* __restrict__ base, const float* __restrict__ f, float alpha, int T)
+{
+    using namespace xee;
+    __shared__ xee_f2 fy[NW][R][64];
+    __shared__ float edge[2][2][NW][64];
+    __shared__ int vote[NW];
+    constexpr int H = NW * R;
+    TileGeom tg;
+    tg.lane = threadIdx.x & 63; tg.w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    tg.x0 = (int)blockIdx.x * (64 - 2 * T) - T;
+    tg.y0 = (int)blockIdx.y * (H - 2 * T) - T;
+    tg.gx = tg.x0 + tg.lane; tg.gy0 = tg.y0 + tg.w * R;
+    tg.col_in = tg.gx >= 0 && tg.gx < g.nx;
+    tg.col_int = tg.gx >= 1 && tg.gx <= g.nx - 2;
+    tg.vx = (tg.lane >= T || tg.x0 <= 0) && (tg.lane < 64 - T || tg.x0 + 63 >= g.nx - 1);
+    tg.mo = (size_t)blockIdx.z * g.plane;
+    tg.ks = (size_t)g.members * g.plane;
+    tg.stamps = nullptr;
+    slim_tile<NW, R, false>(g, tg, fy, edge, vote, psi_in, psi_out, base, f, nullptr, alpha, T, nullptr);
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 int main(int argc, char** argv)
@@ -98,7 +154,12 @@ int main(int argc, char** argv)
     for (int rep = 0; rep < 3; ++rep) {
         CK(hipEventRecord(e0));
         for (int k = 0; k < 10; ++k)
-            if (loop_mode)
+            if (loop_mode == 2)
+                hipLaunchKernelGGL((k_probe_sloop<NW, R>), dim3(256 * per_cu), dim3(NW * 64), 0, 0, g, (k & 1) ? psi1 : psi0, (k & 1) ? psi0 : psi1,
+                                   base, f, 1.0f, T, (int)grid.x, (int)grid.y, swizzle);
+            else if (loop_mode == 3)
+                hipLaunchKernelGGL((k_probe_s1<NW, R>), grid, dim3(NW * 64), 0, 0, g, (k & 1) ? psi1 : psi0, (k & 1) ? psi0 : psi1, base, f, 1.0f, T);
+            else if (loop_mode)
                 hipLaunchKernelGGL((k_probe_loop<NW, R, false>), dim3(256 * per_cu), dim3(NW * 64), 0, 0, g, (k & 1) ? psi1 : psi0, (k & 1) ? psi0 : psi1,
                                    base, f, 1.0f, T, (int)grid.x, (int)grid.y, stagger, swizzle, (unsigned long long*)nullptr);
             else

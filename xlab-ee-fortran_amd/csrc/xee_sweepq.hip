@@ -380,34 +380,17 @@ __global__ __launch_bounds__(NW * 64, (BARO && NW * R <= 64) ? 4 : 1) void k_swe
 //  * the residual of the last step is stored as it is formed: if the tile fails validation the exact body
 //    overwrites the same points.
 // A failed tile is redone by sweep_tile<.., FAST = false> exactly as in k_sweep_q.
-#ifndef XEE_S_MINWAVES
-#define XEE_S_MINWAVES 6
-#endif
+typedef float xee_f2 __attribute__((ext_vector_type(2)));
+
 template <int NW, int R, bool WRITE_R>
-__global__ __launch_bounds__(NW * 64, XEE_S_MINWAVES) void k_sweep_s(Grid g, const float* __restrict__ psi_in,
-        float* __restrict__ psi_out, const float* __restrict__ base, const float* __restrict__ f,
-        float* __restrict__ res, const MemberState* __restrict__ st, float alpha, int T)
+__device__ __forceinline__ void slim_tile(const Grid& g, const TileGeom& tg, xee_f2 (*fy)[R][64] /* [NW]: (f, y1) of each lane's points */,
+        float (*edge)[2][NW][64], int* vote /* [NW] */, const float* __restrict__ psi_in, float* __restrict__ psi_out,
+        const float* __restrict__ base, const float* __restrict__ f, float* __restrict__ res, float alpha, int T,
+        const MemberState* __restrict__ member /* or nullptr */)
 {
     static_assert(R >= 3, "the in-place update keeps two old rows");
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    __shared__ f2 fy[NW][R][64];                          // (f, y1) of this lane's points
-    __shared__ float edge[2][2][NW][64];
-    const int m = blockIdx.z;
-    if (st && !st[m].active) return;                      // workgroup-uniform
+    typedef xee_f2 f2;
     constexpr int H = NW * R;
-    TileGeom tg;
-    tg.lane = threadIdx.x & 63;
-    tg.w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    tg.x0 = (int)blockIdx.x * (64 - 2 * T) - T;
-    tg.y0 = (int)blockIdx.y * (H - 2 * T) - T;
-    tg.gx = tg.x0 + tg.lane;
-    tg.gy0 = tg.y0 + tg.w * R;
-    tg.col_in = tg.gx >= 0 && tg.gx < g.nx;
-    tg.col_int = tg.gx >= 1 && tg.gx <= g.nx - 2;
-    tg.vx = (tg.lane >= T || tg.x0 <= 0) && (tg.lane < 64 - T || tg.x0 + 63 >= g.nx - 1);
-    tg.mo = (size_t)m * g.plane;
-    tg.ks = (size_t)g.members * g.plane;
-    tg.stamps = nullptr;
     const int lane = tg.lane, w = tg.w, gx = tg.gx, gy0 = tg.gy0;
     const size_t mo = tg.mo;
 
@@ -435,6 +418,7 @@ __global__ __launch_bounds__(NW * 64, XEE_S_MINWAVES) void k_sweep_s(Grid g, con
             ap[r] = (apm + o)[cx];
             cq[r] = (cqm + o)[cx];
         }
+        if (member && !member->active) return;              // (workgroup-uniform; looked at only after the loads are issued)
         const int gyb = gy0 - 1;
         if (!(tg.col_in && gyb >= 0 && gyb < g.ny)) cq_b = 0.0f;
 #pragma unroll
@@ -522,8 +506,7 @@ __global__ __launch_bounds__(NW * 64, XEE_S_MINWAVES) void k_sweep_s(Grid g, con
         ok = ok && (!tg.col_int || (amin >= a_lo && amax <= a_hi));
 #pragma unroll
         for (int r = 0; r < R; ++r) ok = ok && __builtin_fabsf(p[r]) <= FLT_MAX;        // false for NaN too
-        // one-barrier vote; the flags go to the exchange slot of the parity nobody reads any more
-        int* vote = reinterpret_cast<int*>(&edge[T & 1][0][0][0]);
+        // one-barrier vote
         const bool wave_bad = __builtin_amdgcn_ballot_w64(!ok) != 0;
         if (lane == 0) vote[w] = wave_bad ? 1 : 0;
         __syncthreads();
@@ -606,6 +589,35 @@ __global__ __launch_bounds__(NW * 64, XEE_S_MINWAVES) void k_sweep_s(Grid g, con
         const bool interior = tg.col_int && gy >= 1 && gy <= g.ny - 2;
         if (tg.vx && vy && interior) psi_out[mo + (size_t)gy * g.pitch + gx] = p[r];
     }
+}
+
+#ifndef XEE_S_MINWAVES
+#define XEE_S_MINWAVES 6
+#endif
+template <int NW, int R, bool WRITE_R>
+__global__ __launch_bounds__(NW * 64, XEE_S_MINWAVES) void k_sweep_s(Grid g, const float* __restrict__ psi_in,
+        float* __restrict__ psi_out, const float* __restrict__ base, const float* __restrict__ f,
+        float* __restrict__ res, const MemberState* __restrict__ st, float alpha, int T)
+{
+    __shared__ xee_f2 fy[NW][R][64];
+    __shared__ float edge[2][2][NW][64];
+    __shared__ int vote[NW];
+    constexpr int H = NW * R;
+    const int m = blockIdx.z;
+    TileGeom tg;
+    tg.lane = threadIdx.x & 63;
+    tg.w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    tg.x0 = (int)blockIdx.x * (64 - 2 * T) - T;
+    tg.y0 = (int)blockIdx.y * (H - 2 * T) - T;
+    tg.gx = tg.x0 + tg.lane;
+    tg.gy0 = tg.y0 + tg.w * R;
+    tg.col_in = tg.gx >= 0 && tg.gx < g.nx;
+    tg.col_int = tg.gx >= 1 && tg.gx <= g.nx - 2;
+    tg.vx = (tg.lane >= T || tg.x0 <= 0) && (tg.lane < 64 - T || tg.x0 + 63 >= g.nx - 1);
+    tg.mo = (size_t)m * g.plane;
+    tg.ks = (size_t)g.members * g.plane;
+    tg.stamps = nullptr;
+    slim_tile<NW, R, WRITE_R>(g, tg, fy, edge, vote, psi_in, psi_out, base, f, res, alpha, T, st ? st + m : nullptr);
 }
 
 // validation kernel for the quotient identity: n pairs per thread drawn from a counter-based generator
