@@ -117,6 +117,11 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal of the multi-rank path on a box with fewer GPUs than ranks (never what the driver runs):
+    # XEE_BENCH_BACKEND=gloo XEE_BENCH_DEVICE=0 puts every rank on one card and gathers the records over gloo
+    backend = os.environ.get("XEE_BENCH_BACKEND", "nccl")
+    if "XEE_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["XEE_BENCH_DEVICE"])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
@@ -125,7 +130,11 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
 
     nr, nz, M = args.nr, args.nz, args.members
     prof = xee.profiles(nr, nz, 0, 0, (0.0, 1.0, 0.0, 1.0))
@@ -146,7 +155,7 @@ def main():
         ens.cal_eta()                          # K5
         rec = ens.ee_scalars()                 # K8
         if world > 1:                          # the one collective of the path: scalar records over RCCL
-            rec = dp.gather_records(rec, world * M, world, rank, device="cuda")
+            rec = dp.gather_records(rec, world * M, world, rank, device=coll_dev)
         return rec
 
     def fence():
@@ -170,7 +179,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 

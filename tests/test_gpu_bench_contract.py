@@ -31,3 +31,21 @@ def test_bench_prints_one_json_line_with_required_keys():
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["value"] > 0 and "sample" in c
     assert d["all_cases_ran_to_max_iter"] is True and d["value"] > 0
+
+
+def test_bench_two_ranks_rehearsal_over_gloo():
+    """The multi-rank path of bench.py (one process per GPU, barrier + max over ranks, record gather) rehearsed with two
+    ranks on ONE card: XEE_BENCH_BACKEND=gloo / XEE_BENCH_DEVICE=0 replace RCCL and the per-rank device, nothing else."""
+    import os
+    port = 29600 + os.getpid() % 300
+    env = dict(os.environ, XEE_BENCH_BACKEND="gloo", XEE_BENCH_DEVICE="0")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2",
+                        "--members", "3", "--nr", "128", "--nz", "64", "--max-iter", "300", "--steps", "1", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["members_per_gpu"] == 3 and d["all_cases_ran_to_max_iter"] is True
+    assert d["value"] > 0 and d["scaling"] == "weak" and d["config"]["parallelism"] == "ensemble-dp2"
