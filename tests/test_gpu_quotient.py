@@ -48,13 +48,13 @@ def _digest(kind, env_extra):
     from the environment once per process)."""
     code = _CASE + f"kind = {kind!r}\n" + r"""
 rng = np.random.default_rng(11)
-nr, nz = 200, 150
+nr, nz = (1024, 512) if 'big' in kind else (200, 150)
 variant = 'BAROCLINIC' if 'clinic' in kind else 'BAROTROPIC'
 A, B, Cc, bc = H.rich_inputs(nr, nz, seed=3)
 if 'tropic' in kind:
     B = np.zeros_like(B)
 forcing = None
-alpha, max_iter = 1.0, 700
+alpha, max_iter = 1.0, (1300 if 'big' in kind else 700)
 if 'zero' in kind:                    # psi = 0, forcing = 0 over most of the plane: zero residuals, signed zeros
     bc = np.zeros_like(bc); bc[:, :3] = -0.0
     forcing = np.zeros((nz, nr), np.float32); forcing[60:70, 80:120] = 1e-9
@@ -84,7 +84,7 @@ print('DIGEST', h.hexdigest(), res['iters'].tolist(), res['err'].tolist(), [str(
 
 
 @pytest.mark.parametrize("kind", ["tropic", "clinic", "tropic-zero", "clinic-zero", "tropic-explode", "clinic-explode",
-                                  "tropic-tiny", "tropic-huge", "tropic-negalpha"])
+                                  "tropic-tiny", "tropic-huge", "tropic-negalpha", "tropic-big", "clinic-big"])
 def test_fast_body_matches_exact_kernel(kind):
     fast = _digest(kind, {})
     exact = _digest(kind, {"XEE_NO_FASTQ": "1"})
