@@ -73,3 +73,26 @@ def test_ensemble_member_zero_is_noise_free_and_deterministic():
     _, B5, _, _ = T.ensemble_member(64, 48, 5)
     _, B5b, _, _ = T.ensemble_member(64, 48, 5)
     assert np.array_equal(B5, B5b) and not np.array_equal(B5, B)
+
+
+def test_sweep_efficiency_round_trip(tmp_path):
+    """records of a source-term sweep -> efficiency.txt per timestep -> read back with the XEffReader key set"""
+    import numpy as np
+    from xlab_ee_fortran_amd import xee as X
+    rec = np.zeros(12, X.RECORD_DTYPE)
+    rng = np.random.default_rng(0)
+    for i in range(12):
+        rec[i]["case_id"] = i
+        rec[i]["sum_Q"] = np.float32(0.05 + (i // 6))
+        rec[i]["sum_Qeta"] = np.float32(rng.standard_normal() * 1e-9)
+    paths = T.write_sweep_efficiency(rec, str(tmp_path))
+    assert len(paths) == 2
+    for t, path in enumerate(paths):
+        raw = T.read_efficiency_raw(path)
+        assert np.float32(raw["sum Q"][0]) == rec[6 * t]["sum_Q"]
+        for (op, rhs), label in T.SWEEP_LABELS.items():
+            k = 3 * ("BAROTROPIC", "BAROCLINIC").index(op) + ("minus_B", "thermal", "rim_bc").index(rhs)
+            assert np.float32(raw[label.strip()][0]) == rec[6 * t + k]["sum_Qeta"]      # ES16.9 round-trips an fp32
+        eff = T.read_efficiency(path)
+        want = (rec[6 * t + 2]["sum_Qeta"] + rec[6 * t + 0]["sum_Qeta"]) / rec[6 * t]["sum_Q"]
+        assert abs(eff["semi_internal"] - float(want)) <= 1e-6 * abs(float(want)) + 1e-30

@@ -99,6 +99,49 @@ def read_efficiency(path):
     return eff
 
 
+# the sweep's cases under the legacy labels (old-diagnose/diagnose.f90:779-841); the three XEffReader keys on
+# are written exactly as it expects them, the baroclinic-operator and thermal lines are additional
+SWEEP_LABELS = {
+    ("BAROTROPIC", "rim_bc"): " eta [L(B=0)    = 0]      w/  boundary",
+    ("BAROTROPIC", "minus_B"): " eta [L(B=0)    = B0]     wo/ boundary",
+    ("BAROTROPIC", "thermal"): " eta [L(B=0)    = J Q]    wo/ boundary",
+    ("BAROCLINIC", "rim_bc"): " eta [L(B=B0dB) = 0]      w/  boundary",
+    ("BAROCLINIC", "minus_B"): " eta [L(B=B0dB) = B0]     wo/ boundary",
+    ("BAROCLINIC", "thermal"): " eta [L(B=B0dB) = J Q]    wo/ boundary",
+}
+
+
+def write_efficiency(path, sum_Q, entries, elapsed=None):
+    """efficiency.txt in the legacy layout: `entries` = [(label, sum_Qeta)], each written as
+    ` <label> : <sum_Qeta> , <sum_Qeta / sum_Q>` with ES16.9 numbers (an fp32 value round-trips)."""
+    with open(path, "w") as fh:
+        if elapsed is not None:
+            fh.write(" Time elapsed (sec)                          : %16.9E\n" % elapsed)
+        fh.write(" sum Q                                       : %16.9E\n" % float(sum_Q))
+        for label, v in entries:
+            ratio = float(np.float32(v) / np.float32(sum_Q)) if sum_Q != 0 else float("nan")
+            fh.write("%s : %16.9E , %16.9E\n" % (label, float(v), ratio))
+
+
+def write_sweep_efficiency(records, outdir, op_names=("BAROTROPIC", "BAROCLINIC"), rhs_names=("minus_B", "thermal", "rim_bc")):
+    """One efficiency.txt per timestep of a source-term sweep (sweep.run records: case id = 6 t + 3 op + rhs)
+    under `outdir/t%04d/`; returns the paths."""
+    per = len(op_names) * len(rhs_names)
+    paths = []
+    for t in range(len(records) // per):
+        block = {int(r["case_id"]) - per * t: r for r in records[per * t: per * (t + 1)]}
+        d = os.path.join(outdir, "t%04d" % t)
+        os.makedirs(d, exist_ok=True)
+        entries = []
+        for o, op in enumerate(op_names):
+            for k, rhs in enumerate(rhs_names):
+                entries.append((SWEEP_LABELS[(op, rhs)], block[len(rhs_names) * o + k]["sum_Qeta"]))
+        path = os.path.join(d, "efficiency.txt")
+        write_efficiency(path, block[0]["sum_Q"], entries)
+        paths.append(path)
+    return paths
+
+
 def read_efficiency_raw(path):
     """All `label : value[, ratio]` lines -> {label: (value, ratio or None)} (labels stripped)."""
     out = {}
