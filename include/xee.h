@@ -153,6 +153,21 @@ int xee_fd_stencil(int which, const float *from, float *to, const float *ra, con
 int xee_exchange_conversion(const float *rpsi, const float *rchi, const float *rhoC, const float *ra,
                             const float *za, const float *rho, float *bndconv, float *sum, int nr, int nz);
 
+/* Stage II of the legacy TENDENCY mode (src/old-diagnose/diagnose.f90:462-518): forecast of the thermal field
+ * between the two inversions.  Grids: A (nr-1,nz), B (nr-1,nz-1), C (nr,nz-1), packed, i fastest.
+ * replaces the loop at :470-479: dtheta/dt = J - theta0/g0 (rhoA w)-bar-z + theta0/g0 (rhoB u)-bar-r on B cells */
+int xee_theta_tendency(const float *JJ_B, const float *rhoA_A, const float *w_A, const float *rhoB_C, const float *u_C,
+                       float *dtheta_dt_B, int nr, int nz);
+/* replaces relativeTheta, :893-912: theta0 at (1,1), integrated along r on the first row, then up every column */
+int xee_relative_theta(const float *dtheta_dz_A, const float *dtheta_dr_C, const float *ra, const float *za,
+                       float *theta_B, int nr, int nz);
+/* replaces :489-518.  theta_B in: dtheta/dt, out: the forecast theta; rhoB_B, rhoA_A, rhoB_C updated in place;
+ * b_anomaly_B and solver_b_anomaly_B written.  One deliberate difference: the legacy code adds to row nz-1 of rhoA_A a
+ * workspace row d_dz_B2A never wrote (uninitialised); that row is left alone here. */
+int xee_theta_anomaly_update(float *theta_B, float testing_dt, float *rhoB_B, float *rhoA_A, float *rhoB_C,
+                             float *b_anomaly_B, float *solver_b_anomaly_B, const float *ra, const float *za,
+                             const float *rcuva, const float *rho, int nr, int nz);
+
 /* ---------------------------------------------------------------------------------------------
  * Tier 2 -- device-resident ensemble of independent cases on ONE GPU.
  * All members share nr, nz and the 1-D profiles; each has its own A, B, C, forcing, bc_init, Q.

@@ -563,3 +563,70 @@ float orc_exchange_conversion(const float *rpsi, const float *rchi, const float 
     }
     return sum;
 }
+
+/* src/old-diagnose/diagnose.f90:470-479.  `theta0/g0 * (x) / 2.0` is ((theta0/g0) * x) / 2.0, the sum left to right. */
+void orc_theta_tendency(const float *JJ_B, const float *rhoA_A, const float *w_A, const float *rhoB_C,
+                        const float *u_C, float *dtheta_dt_B, int nr, int nz)
+{
+    orc_constants_t k;
+    orc_constants(&k);
+    const float c = k.theta0 / k.g0;
+    for (int j = 0; j < nz - 1; ++j)
+        for (int i = 0; i < nr - 1; ++i) {
+            float a = c * (rhoA_A[IDX(i, j, nr - 1)] * w_A[IDX(i, j, nr - 1)]
+                           + rhoA_A[IDX(i, j + 1, nr - 1)] * w_A[IDX(i, j + 1, nr - 1)]) / 2.0f;
+            float b = c * (rhoB_C[IDX(i, j, nr)] * u_C[IDX(i, j, nr)]
+                           + rhoB_C[IDX(i + 1, j, nr)] * u_C[IDX(i + 1, j, nr)]) / 2.0f;
+            dtheta_dt_B[IDX(i, j, nr - 1)] = JJ_B[IDX(i, j, nr - 1)] - a + b;
+        }
+}
+
+/* src/old-diagnose/diagnose.f90:893-912: integrate the gradients from theta0 at (1,1): along r on the first
+ * row, then up every column; sequential fp32 additions. */
+void orc_relative_theta(float *theta_B, const float *dtheta_dz_A, const float *dtheta_dr_C,
+                        const float *ra, const float *za, int nr, int nz)
+{
+    orc_constants_t k;
+    orc_constants(&k);
+    for (size_t q = 0; q < (size_t)(nr - 1) * (nz - 1); ++q) theta_B[q] = k.theta0;
+    for (int i = 1; i <= nr - 2; ++i) {
+        float dist = (ra[i + 1] - ra[i - 1]) / 2.0f;
+        theta_B[IDX(i, 0, nr - 1)] = theta_B[IDX(i - 1, 0, nr - 1)] + dist * dtheta_dr_C[IDX(i, 0, nr)];
+    }
+    for (int i = 0; i < nr - 1; ++i)
+        for (int j = 1; j <= nz - 2; ++j) {
+            float dist = (za[j + 1] - za[j - 1]) / 2.0f;
+            theta_B[IDX(i, j, nr - 1)] = theta_B[IDX(i, j - 1, nr - 1)] + dist * dtheta_dz_A[IDX(i, j, nr - 1)];
+        }
+}
+
+/* src/old-diagnose/diagnose.f90:489-518 (see the header for the one deliberate difference) */
+void orc_theta_anomaly_update(float *theta_B, float testing_dt, float *rhoB_B, float *rhoA_A, float *rhoB_C,
+                              float *b_anomaly_B, float *solver_b_anomaly_B, const float *ra, const float *za,
+                              const float *rcuva, const float *rho, int nr, int nz)
+{
+    orc_constants_t k;
+    orc_constants(&k);
+    const size_t nB = (size_t)(nr - 1) * (nz - 1), nA = (size_t)(nr - 1) * nz, nC = (size_t)nr * (nz - 1);
+    float *wB = (float *)calloc(nB, sizeof(float)), *wA = (float *)calloc(nA, sizeof(float));
+    float *gA = (float *)malloc(nA * sizeof(float)), *gC = (float *)malloc(nC * sizeof(float));
+    for (size_t q = 0; q < nB; ++q) theta_B[q] = theta_B[q] * testing_dt;                          /* :489 */
+    orc_d_dr_B2B(theta_B, wB, ra, nr, nz);                                                         /* :492 */
+    for (size_t q = 0; q < nB; ++q) b_anomaly_B[q] = -(k.g0 / k.theta0 * wB[q]);                   /* :493 */
+    for (size_t q = 0; q < nB; ++q) rhoB_B[q] = rhoB_B[q] + b_anomaly_B[q];                        /* :494 */
+    orc_d_dz_B2A(theta_B, wA, za, nr, nz);                                                         /* :499 */
+    for (int j = 1; j <= nz - 3; ++j)                                                              /* :500 */
+        for (int i = 0; i < nr - 1; ++i)
+            rhoA_A[IDX(i, j, nr - 1)] = rhoA_A[IDX(i, j, nr - 1)] + k.g0 / k.theta0 * wA[IDX(i, j, nr - 1)];
+    for (int j = 0; j < nz - 1; ++j)                                                               /* :503-508 */
+        for (int i = 1; i <= nr - 2; ++i)
+            rhoB_C[IDX(i, j, nr)] = (rhoB_B[IDX(i - 1, j, nr - 1)] + rhoB_B[IDX(i, j, nr - 1)]) / 2.0f;
+    for (size_t q = 0; q < nA; ++q) gA[q] = rhoA_A[q] * (k.theta0 / k.g0);                         /* :509 */
+    for (size_t q = 0; q < nC; ++q) gC[q] = rhoB_C[q] * (-k.theta0 / k.g0);
+    orc_relative_theta(theta_B, gA, gC, ra, za, nr, nz);
+    for (int j = 0; j < nz - 1; ++j)                                                               /* :513-518 */
+        for (int i = 0; i < nr - 1; ++i)
+            solver_b_anomaly_B[IDX(i, j, nr - 1)] = b_anomaly_B[IDX(i, j, nr - 1)]
+                                                    / ((rcuva[i] + rcuva[i + 1]) / 2.0f) / ((rho[j] + rho[j + 1]) / 2.0f);
+    free(wB); free(wA); free(gA); free(gC);
+}

@@ -122,6 +122,21 @@ float orc_exchange_conversion(const float *rpsi, const float *rchi, const float 
                               float *bndconv, const float *ra, const float *za,
                               const float *rho, int nr, int nz);
 
+/* ---- legacy TENDENCY mode, Stage II (src/old-diagnose/diagnose.f90:462-518): forecast of the thermal field.
+ * parity unpinned against the legacy binary (it has undefined behaviour elsewhere); restated from
+ * the source lines cited at each function.  Grids: A (nr-1,nz), B (nr-1,nz-1), C (nr,nz-1). */
+void orc_theta_tendency(const float *JJ_B, const float *rhoA_A, const float *w_A, const float *rhoB_C,
+                        const float *u_C, float *dtheta_dt_B, int nr, int nz);                      /* :470-479 */
+void orc_relative_theta(float *theta_B, const float *dtheta_dz_A, const float *dtheta_dr_C,
+                        const float *ra, const float *za, int nr, int nz);                          /* :893-912 */
+/* :489-518: theta := dtheta_dt * testing_dt; b anomaly = -g0/theta0 * d_dr_B2B(theta), added to rhoB_B; rhoA_A rows
+ * 2..nz-2 += g0/theta0 * d_dz_B2A(theta) (the legacy code also adds row nz-1 of a workspace d_dz_B2A never wrote:
+ * that row is left alone here); rhoB_C(2:nr-1,:) re-averaged from rhoB_B; theta := relativeTheta(...);
+ * solver_b_anomaly_B = b anomaly / rcuv-bar / rho-bar. */
+void orc_theta_anomaly_update(float *theta_B, float testing_dt, float *rhoB_B, float *rhoA_A, float *rhoB_C,
+                              float *b_anomaly_B, float *solver_b_anomaly_B, const float *ra, const float *za,
+                              const float *rcuva, const float *rho, int nr, int nz);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,3 +58,31 @@ def test_rhs_momentum_and_exchange_conversion():
     s_w = np.float32(H.oracle().orc_exchange_conversion(rpsi, rchi, rhoC, bnd_w, prof["ra"], prof["za"], prof["rho"], nr, nz))
     bnd, s = X.exchange_conversion(rpsi, rchi, rhoC, prof)
     assert biteq(bnd, bnd_w) and s.tobytes() == s_w.tobytes()
+
+
+@pytest.mark.parametrize("nr,nz", [(72, 50), (37, 29), (130, 21)])
+def test_legacy_stage_two_thermal_forecast(nr, nz):
+    """Stage II of the legacy TENDENCY mode (old-diagnose/diagnose.f90:462-518): dtheta/dt, the anomaly update chain and
+    relativeTheta on the GPU, bit for bit against the oracle's restatement (parity unpinned against the legacy binary)."""
+    rng = np.random.default_rng(nr * 7 + nz)
+    prof = H.profiles(nr, nz, 0, 0, (1.0e3, 2.0e5, 0.0, 1.5e4))
+    f32 = lambda *shape: rng.standard_normal(shape).astype(np.float32)
+    JJ, rhoA, wA, rhoBC, uC = f32(nz - 1, nr - 1), f32(nz, nr - 1) * 1e-4, f32(nz, nr - 1), f32(nz - 1, nr) * 1e-6, f32(nz - 1, nr)
+    L = H.oracle()
+    want = np.zeros((nz - 1, nr - 1), np.float32)
+    L.orc_theta_tendency(JJ, rhoA, wA, rhoBC, uC, want, nr, nz)
+    got = X.theta_tendency(JJ, rhoA, wA, rhoBC, uC)
+    assert biteq(got, want)
+
+    dzA, drC = f32(nz, nr - 1) * 1e-3, f32(nz - 1, nr) * 1e-5
+    want = np.zeros((nz - 1, nr - 1), np.float32)
+    L.orc_relative_theta(want, dzA, drC, prof["ra"], prof["za"], nr, nz)
+    assert biteq(X.relative_theta(dzA, drC, prof), want)
+
+    rhoBB = f32(nz - 1, nr - 1) * 1e-6
+    th, bb, ra_, rc = got.copy(), rhoBB.copy(), rhoA.copy(), rhoBC.copy()
+    ban, sb = np.zeros_like(th), np.zeros_like(th)
+    L.orc_theta_anomaly_update(th, 3600.0, bb, ra_, rc, ban, sb, prof["ra"], prof["za"], prof["rcuva"], prof["rho"], nr, nz)
+    out = X.theta_anomaly_update(got, 3600.0, rhoBB, rhoA, rhoBC, prof)
+    for name, ref in (("theta", th), ("rhoB_B", bb), ("rhoA_A", ra_), ("rhoB_C", rc), ("b_anomaly", ban), ("solver_b_anomaly", sb)):
+        assert biteq(out[name], ref), name

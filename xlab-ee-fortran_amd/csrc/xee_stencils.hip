@@ -4,6 +4,8 @@
 //                           (identical copies in src/old-diagnose/diagnose.f90:943-1027)
 //   xee_rhs_momentum        RHS_rpsi_mom, src/old-diagnose/diagnose.f90:412-436
 //   xee_exchange_conversion boundary exchange-conversion line integral, old-diagnose :1143-1174 (K9)
+//   xee_theta_tendency, xee_relative_theta, xee_theta_anomaly_update   Stage II of the legacy TENDENCY mode,
+//                           old-diagnose :462-518, :893-912 (forecast of the thermal field)
 // Same bit-exactness discipline as xee_kernels.hip (no contraction, left-to-right, IEEE division).
 #include "../../include/xee.h"
 #include "xee_device.h"
@@ -159,9 +161,151 @@ __global__ void k_exchange_sum(const float* __restrict__ bndconv, const float* _
     out[0] = s;
 }
 
+// ---- legacy TENDENCY mode, Stage II (src/old-diagnose/diagnose.f90:462-518) -----------------------------------
+__device__ __forceinline__ float s_g0() { return 9.8f; }        // xtt-lib-fortran/constants.f90:4
+__device__ __forceinline__ float s_theta0() { return 298.0f; }
+
+// :470-479  dtheta/dt on B cells; `theta0/g0 * (x) / 2.0` = ((theta0/g0) * x) / 2.0
+__global__ __launch_bounds__(256) void k_theta_tendency(const float* __restrict__ JJ, const float* __restrict__ rhoA,
+        const float* __restrict__ wA, const float* __restrict__ rhoBC, const float* __restrict__ uC,
+        float* __restrict__ out, int nr, int nz)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+    if (i >= nr - 1 || j >= nz - 1) return;
+    const float c = s_theta0() / s_g0();
+    const size_t a0 = (size_t)j * (nr - 1) + i, a1 = (size_t)(j + 1) * (nr - 1) + i, c0 = (size_t)j * nr + i;
+    const float a = c * (rhoA[a0] * wA[a0] + rhoA[a1] * wA[a1]) / 2.0f;
+    const float b = c * (rhoBC[c0] * uC[c0] + rhoBC[c0 + 1] * uC[c0 + 1]) / 2.0f;
+    out[a0] = JJ[a0] - a + b;
+}
+
+__global__ __launch_bounds__(256) void k_scale(float* __restrict__ x, float s, size_t n)
+{
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (q < n) x[q] = x[q] * s;
+}
+
+// :492-494  b anomaly = -(g0/theta0 * d_dr_B2B(theta)); rhoB_B += b anomaly;  :513-518 solver_b_anomaly
+__global__ __launch_bounds__(256) void k_b_anomaly(const float* __restrict__ theta, float* __restrict__ banom,
+        float* __restrict__ rhoBB, float* __restrict__ sban, const float* __restrict__ ra,
+        const float* __restrict__ rcuva, const float* __restrict__ rho, int nr, int nz)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+    if (i >= nr - 1 || j >= nz - 1) return;
+    const int m = (i == 0) ? 0 : -1, n = (i == nr - 2) ? 0 : 1;                         // d_dr_B2B, quick-tools2.f90:31-42
+    const size_t o = (size_t)j * (nr - 1) + i;
+    const float d = (theta[o + m] - theta[o + n]) / (ra[i + m] - ra[i + n]);
+    const float b = -(s_g0() / s_theta0() * d);
+    banom[o] = b;
+    rhoBB[o] = rhoBB[o] + b;
+    sban[o] = b / ((rcuva[i] + rcuva[i + 1]) / 2.0f) / ((rho[j] + rho[j + 1]) / 2.0f);
+}
+
+// :499-500  rhoA_A rows 2..nz-2 += g0/theta0 * d_dz_B2A(theta)
+__global__ __launch_bounds__(256) void k_rhoA_update(const float* __restrict__ theta, float* __restrict__ rhoA,
+        const float* __restrict__ za, int nr, int nz)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+    if (i >= nr - 1 || j < 1 || j > nz - 3) return;
+    const size_t o = (size_t)j * (nr - 1) + i;
+    const float d = (theta[o] - theta[o - (nr - 1)]) / ((za[j + 1] - za[j - 1]) / 2.0f);  // d_dz_B2A, quick-tools2.f90:7-12
+    rhoA[o] = rhoA[o] + s_g0() / s_theta0() * d;
+}
+
+// :503-508  rhoB_C(I,J) = (rhoB_B(I-1,J) + rhoB_B(I,J)) / 2, I = 2..nr-1
+__global__ __launch_bounds__(256) void k_rhoBC_update(const float* __restrict__ rhoBB, float* __restrict__ rhoBC, int nr, int nz)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+    if (i < 1 || i > nr - 2 || j >= nz - 1) return;
+    rhoBC[(size_t)j * nr + i] = (rhoBB[(size_t)j * (nr - 1) + i - 1] + rhoBB[(size_t)j * (nr - 1) + i]) / 2.0f;
+}
+
+// :893-912 relativeTheta: one lane integrates along the first row, then one lane per column integrates upwards;
+// the gradients are scaled on the fly (gz = dz_A * sz, gr = dr_C * sr) as the caller's array expressions do
+__global__ void k_relative_theta_row(float* __restrict__ theta, const float* __restrict__ drC, float sr,
+        const float* __restrict__ ra, int nr)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    float t = s_theta0();
+    theta[0] = t;
+    for (int i = 1; i <= nr - 2; ++i) {
+        const float dist = (ra[i + 1] - ra[i - 1]) / 2.0f;
+        t = t + dist * (drC[i] * sr);
+        theta[i] = t;
+    }
+}
+__global__ __launch_bounds__(64) void k_relative_theta_cols(float* __restrict__ theta, const float* __restrict__ dzA, float sz,
+        const float* __restrict__ za, int nr, int nz)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= nr - 1) return;
+    float t = theta[i];
+    for (int j = 1; j <= nz - 2; ++j) {
+        const float dist = (za[j + 1] - za[j - 1]) / 2.0f;
+        t = t + dist * (dzA[(size_t)j * (nr - 1) + i] * sz);
+        theta[(size_t)j * (nr - 1) + i] = t;
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int xee_theta_tendency(const float* JJ_B, const float* rhoA_A, const float* w_A, const float* rhoB_C, const float* u_C,
+                       float* dtheta_dt_B, int nr, int nz)
+{
+    if (!JJ_B || !rhoA_A || !w_A || !rhoB_C || !u_C || !dtheta_dt_B || nr < 3 || nz < 4)
+        return record_failure(XEE_ERR_INVALID_ARGUMENT, "xee_theta_tendency: bad argument");
+    TRY(need_device());
+    const size_t nB = (size_t)(nr - 1) * (nz - 1), nA = (size_t)(nr - 1) * nz, nC = (size_t)nr * (nz - 1);
+    DevBuf dJ, dRA, dW, dRC, dU, dO;
+    TRY(dJ.put(JJ_B, nB)); TRY(dRA.put(rhoA_A, nA)); TRY(dW.put(w_A, nA)); TRY(dRC.put(rhoB_C, nC)); TRY(dU.put(u_C, nC));
+    TRY(dO.put(nullptr, nB));
+    hipLaunchKernelGGL(k_theta_tendency, dim3((nr + 63) / 64, (nz + 3) / 4), dim3(64, 4), 0, 0, dJ.p, dRA.p, dW.p, dRC.p, dU.p, dO.p, nr, nz);
+    TRY(finish("xee_theta_tendency"));
+    return dO.get(dtheta_dt_B);
+}
+
+int xee_relative_theta(const float* dtheta_dz_A, const float* dtheta_dr_C, const float* ra, const float* za,
+                       float* theta_B, int nr, int nz)
+{
+    if (!dtheta_dz_A || !dtheta_dr_C || !ra || !za || !theta_B || nr < 3 || nz < 4)
+        return record_failure(XEE_ERR_INVALID_ARGUMENT, "xee_relative_theta: bad argument");
+    TRY(need_device());
+    DevBuf dA, dC, dra, dza, dT;
+    TRY(dA.put(dtheta_dz_A, (size_t)(nr - 1) * nz)); TRY(dC.put(dtheta_dr_C, (size_t)nr * (nz - 1)));
+    TRY(dra.put(ra, nr)); TRY(dza.put(za, nz)); TRY(dT.put(nullptr, (size_t)(nr - 1) * (nz - 1)));
+    hipLaunchKernelGGL(k_relative_theta_row, dim3(1), dim3(64), 0, 0, dT.p, dC.p, 1.0f, dra.p, nr);
+    hipLaunchKernelGGL(k_relative_theta_cols, dim3((nr + 63) / 64), dim3(64), 0, 0, dT.p, dA.p, 1.0f, dza.p, nr, nz);
+    TRY(finish("xee_relative_theta"));
+    return dT.get(theta_B);
+}
+
+int xee_theta_anomaly_update(float* theta_B, float testing_dt, float* rhoB_B, float* rhoA_A, float* rhoB_C,
+                             float* b_anomaly_B, float* solver_b_anomaly_B, const float* ra, const float* za,
+                             const float* rcuva, const float* rho, int nr, int nz)
+{
+    if (!theta_B || !rhoB_B || !rhoA_A || !rhoB_C || !b_anomaly_B || !solver_b_anomaly_B || !ra || !za || !rcuva || !rho ||
+        nr < 3 || nz < 4)
+        return record_failure(XEE_ERR_INVALID_ARGUMENT, "xee_theta_anomaly_update: bad argument");
+    TRY(need_device());
+    const size_t nB = (size_t)(nr - 1) * (nz - 1), nA = (size_t)(nr - 1) * nz, nC = (size_t)nr * (nz - 1);
+    DevBuf dT, dBB, dRA, dRC, dBa, dSb, dra, dza, drc, drho;
+    TRY(dT.put(theta_B, nB)); TRY(dBB.put(rhoB_B, nB)); TRY(dRA.put(rhoA_A, nA)); TRY(dRC.put(rhoB_C, nC));
+    TRY(dBa.put(nullptr, nB)); TRY(dSb.put(nullptr, nB));
+    TRY(dra.put(ra, nr)); TRY(dza.put(za, nz)); TRY(drc.put(rcuva, nr)); TRY(drho.put(rho, nz));
+    const dim3 grid((nr + 63) / 64, (nz + 3) / 4), block(64, 4);
+    hipLaunchKernelGGL(k_scale, dim3((unsigned)((nB + 255) / 256)), dim3(256), 0, 0, dT.p, testing_dt, nB);                  // :489
+    hipLaunchKernelGGL(k_b_anomaly, grid, block, 0, 0, dT.p, dBa.p, dBB.p, dSb.p, dra.p, drc.p, drho.p, nr, nz);          // :492-494, :513-518
+    hipLaunchKernelGGL(k_rhoA_update, grid, block, 0, 0, dT.p, dRA.p, dza.p, nr, nz);                                      // :499-500
+    hipLaunchKernelGGL(k_rhoBC_update, grid, block, 0, 0, dBB.p, dRC.p, nr, nz);                                           // :503-508
+    // :509 relativeTheta(theta, rhoA_A * (theta0/g0), rhoB_C * (-theta0/g0))
+    hipLaunchKernelGGL(k_relative_theta_row, dim3(1), dim3(64), 0, 0, dT.p, dRC.p, -298.0f / 9.8f, dra.p, nr);
+    hipLaunchKernelGGL(k_relative_theta_cols, dim3((nr + 63) / 64), dim3(64), 0, 0, dT.p, dRA.p, 298.0f / 9.8f, dza.p, nr, nz);
+    TRY(finish("xee_theta_anomaly_update"));
+    TRY(dT.get(theta_B)); TRY(dBB.get(rhoB_B)); TRY(dRA.get(rhoA_A)); TRY(dRC.get(rhoB_C)); TRY(dBa.get(b_anomaly_B));
+    return dSb.get(solver_b_anomaly_B);
+}
 
 int xee_fd_stencil(int which, const float* from, float* to, const float* ra, const float* za, const float* rcuva,
                    int nr, int nz)

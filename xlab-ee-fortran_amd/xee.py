@@ -107,6 +107,10 @@ def lib():
     L.xee_ensemble_records.argtypes = [vp, C.c_void_p]
     L.xee_ensemble_timing.argtypes = [vp, C.POINTER(Timing)]
     L.xee_ensemble_time_sweeps.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.xee_theta_tendency.argtypes = [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int]
+    L.xee_relative_theta.argtypes = [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int]
+    L.xee_theta_anomaly_update.argtypes = [_f32p, C.c_float, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p,
+                                           C.c_int, C.c_int]
     L.xee_quotient_selfcheck.argtypes = [C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
     _lib = L
@@ -272,6 +276,32 @@ def exchange_conversion(rpsi, rchi, rhoC, prof):
 
 
 # ---- Tier 2: device-resident ensemble ---------------------------------------------------------
+
+def theta_tendency(JJ_B, rhoA_A, w_A, rhoB_C, u_C):
+    """old-diagnose/diagnose.f90:470-479 -> dtheta/dt on B cells (nz-1, nr-1)."""
+    nzm, nrm = JJ_B.shape
+    out = np.zeros((nzm, nrm), np.float32)
+    _chk(lib().xee_theta_tendency(_a(JJ_B), _a(rhoA_A), _a(w_A), _a(rhoB_C), _a(u_C), out, nrm + 1, nzm + 1))
+    return out
+
+
+def relative_theta(dtheta_dz_A, dtheta_dr_C, prof):
+    """old-diagnose/diagnose.f90:893-912 (relativeTheta) -> theta on B cells."""
+    nz, nrm = dtheta_dz_A.shape
+    out = np.zeros((nz - 1, nrm), np.float32)
+    _chk(lib().xee_relative_theta(_a(dtheta_dz_A), _a(dtheta_dr_C), prof["ra"], prof["za"], out, nrm + 1, nz))
+    return out
+
+
+def theta_anomaly_update(dtheta_dt_B, testing_dt, rhoB_B, rhoA_A, rhoB_C, prof):
+    """old-diagnose/diagnose.f90:489-518 -> dict(theta, rhoB_B, rhoA_A, rhoB_C, b_anomaly, solver_b_anomaly); inputs are not modified."""
+    nzm, nrm = dtheta_dt_B.shape
+    th, bb, ra_, rc = (np.array(_a(x), copy=True) for x in (dtheta_dt_B, rhoB_B, rhoA_A, rhoB_C))
+    ban, sb = np.zeros((nzm, nrm), np.float32), np.zeros((nzm, nrm), np.float32)
+    _chk(lib().xee_theta_anomaly_update(th, float(testing_dt), bb, ra_, rc, ban, sb, prof["ra"], prof["za"], prof["rcuva"],
+                                        prof["rho"], nrm + 1, nzm + 1))
+    return {"theta": th, "rhoB_B": bb, "rhoA_A": ra_, "rhoB_C": rc, "b_anomaly": ban, "solver_b_anomaly": sb}
+
 
 def quotient_selfcheck(seed, blocks, per_thread, d_exp_lo, d_exp_hi, device=-1):
     """Count the operand pairs on which the blocked sweep's hoisted-reciprocal quotient differs from the IEEE
