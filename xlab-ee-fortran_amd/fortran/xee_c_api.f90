@@ -153,6 +153,36 @@ interface
         integer(c_int), value :: nr, nz
         integer(c_int) :: st
     end function
+
+    ! Stage II of the legacy TENDENCY mode (old-diagnose/diagnose.f90:462-518, :893-912)
+    function xee_theta_tendency(JJ_B, rhoA_A, w_A, rhoB_C, u_C, dtheta_dt_B, nr, nz)   &
+        &                       bind(C, name="xee_theta_tendency") result(st)
+        import :: c_int, c_float
+        real(c_float), intent(in) :: JJ_B(*), rhoA_A(*), w_A(*), rhoB_C(*), u_C(*)
+        real(c_float), intent(out) :: dtheta_dt_B(*)
+        integer(c_int), value :: nr, nz
+        integer(c_int) :: st
+    end function
+
+    function xee_relative_theta(dtheta_dz_A, dtheta_dr_C, ra, za, theta_B, nr, nz)   &
+        &                       bind(C, name="xee_relative_theta") result(st)
+        import :: c_int, c_float
+        real(c_float), intent(in) :: dtheta_dz_A(*), dtheta_dr_C(*), ra(*), za(*)
+        real(c_float), intent(out) :: theta_B(*)
+        integer(c_int), value :: nr, nz
+        integer(c_int) :: st
+    end function
+
+    function xee_theta_anomaly_update(theta_B, testing_dt, rhoB_B, rhoA_A, rhoB_C, b_anomaly_B, solver_b_anomaly_B,   &
+        &                             ra, za, rcuva, rho, nr, nz) bind(C, name="xee_theta_anomaly_update") result(st)
+        import :: c_int, c_float
+        real(c_float), intent(inout) :: theta_B(*), rhoB_B(*), rhoA_A(*), rhoB_C(*)
+        real(c_float), value :: testing_dt
+        real(c_float), intent(out) :: b_anomaly_B(*), solver_b_anomaly_B(*)
+        real(c_float), intent(in) :: ra(*), za(*), rcuva(*), rho(*)
+        integer(c_int), value :: nr, nz
+        integer(c_int) :: st
+    end function
 end interface
 
 contains
