@@ -168,6 +168,14 @@ int xee_theta_anomaly_update(float *theta_B, float testing_dt, float *rhoB_B, fl
                              float *b_anomaly_B, float *solver_b_anomaly_B, const float *ra, const float *za,
                              const float *rcuva, const float *rho, int nr, int nz);
 
+/* replaces the m2 integration, src/old-diagnose/diagnose.f90:359-380, in its INTENDED form (the legacy lines read
+ * m2(0,j) and use stale loop indices in the first column): m2(1,j) from its own row, then
+ * m2(i,j) = m2(i-1,j) + rcuva(i)**3.0 * rhoC_C(i,j) * (ra(i+1)-ra(i-1)) / 2.0 [/ sin_table(i)], a sequential fp32 sum along r.
+ * rhoC_C (nr,nz-1) -> m2_B (nr-1,nz-1); sin_table NULL for the cylindrical geometry.  The powers (glibc powf on the
+ * 1-D profile, as the Fortran runtime does) are taken on the host. */
+int xee_m2_from_C(const float *rhoC_C, const float *ra, const float *rcuva, const float *sin_table, float *m2_B,
+                  int nr, int nz);
+
 /* ---------------------------------------------------------------------------------------------
  * Tier 2 -- device-resident ensemble of independent cases on ONE GPU.
  * All members share nr, nz and the 1-D profiles; each has its own A, B, C, forcing, bc_init, Q.

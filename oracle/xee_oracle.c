@@ -630,3 +630,19 @@ void orc_theta_anomaly_update(float *theta_B, float testing_dt, float *rhoB_B, f
                                                     / ((rcuva[i] + rcuva[i + 1]) / 2.0f) / ((rho[j] + rho[j + 1]) / 2.0f);
     free(wB); free(wA); free(gA); free(gC);
 }
+
+/* src/old-diagnose/diagnose.f90:359-380, intended form (see the header).  `x**3.0` is powf, as flang lowers it. */
+void orc_m2_from_C(const float *rhoC_C, float *m2_B, const float *ra, const float *rcuva, const float *sin_table,
+                   int nr, int nz)
+{
+    for (int j = 0; j < nz - 1; ++j) {
+        float first = powf((rcuva[1] - rcuva[0]) / 4.0f, 3.0f) * rhoC_C[IDX(0, j, nr)] * (ra[1] - ra[0]) / 2.0f;     /* :361,:372 */
+        if (sin_table) first = first / ((sin_table[1] + 3.0f * sin_table[0]) / 4.0f);                                /* :373 */
+        m2_B[IDX(0, j, nr - 1)] = first;
+        for (int i = 1; i <= nr - 2; ++i) {
+            float t = powf(rcuva[i], 3.0f) * rhoC_C[IDX(i, j, nr)] * (ra[i + 1] - ra[i - 1]) / 2.0f;                 /* :365,:377 */
+            if (sin_table) t = t / sin_table[i];                                                                     /* :378 */
+            m2_B[IDX(i, j, nr - 1)] = m2_B[IDX(i - 1, j, nr - 1)] + t;
+        }
+    }
+}

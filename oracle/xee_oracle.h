@@ -137,6 +137,13 @@ void orc_theta_anomaly_update(float *theta_B, float testing_dt, float *rhoB_B, f
                               float *b_anomaly_B, float *solver_b_anomaly_B, const float *ra, const float *za,
                               const float *rcuva, const float *rho, int nr, int nz);
 
+/* src/old-diagnose/diagnose.f90:359-380: angular momentum squared on B cells by integrating rcuv^3 * C along r.
+ * The legacy lines read out of bounds (m2(i-1,j) with i = 1 in the cylindrical loop) and use stale loop indices in
+ * the first column (rhoC_C(i,j) after the previous loops); restated as INTENDED: the first column from its own row,
+ * the recurrence from the second column on.  sin_table may be NULL (cylindrical).  parity unpinned. */
+void orc_m2_from_C(const float *rhoC_C, float *m2_B, const float *ra, const float *rcuva, const float *sin_table,
+                   int nr, int nz);
+
 #ifdef __cplusplus
 }
 #endif

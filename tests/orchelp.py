@@ -75,6 +75,7 @@ def oracle():
     L.orc_f_from_B.argtypes = [f32p, f32p, i32, i32]
     L.orc_exchange_conversion.argtypes = [f32p] * 7 + [i32, i32]
     L.orc_exchange_conversion.restype = f32
+    L.orc_m2_from_C.argtypes = [f32p, f32p, f32p, f32p, C.c_void_p, i32, i32]
     L.orc_theta_tendency.argtypes = [f32p] * 6 + [i32, i32]
     L.orc_relative_theta.argtypes = [f32p] * 5 + [i32, i32]
     L.orc_theta_anomaly_update.argtypes = [f32p, f32] + [f32p] * 9 + [i32, i32]

@@ -86,3 +86,16 @@ def test_legacy_stage_two_thermal_forecast(nr, nz):
     out = X.theta_anomaly_update(got, 3600.0, rhoBB, rhoA, rhoBC, prof)
     for name, ref in (("theta", th), ("rhoB_B", bb), ("rhoA_A", ra_), ("rhoB_C", rc), ("b_anomaly", ban), ("solver_b_anomaly", sb)):
         assert biteq(out[name], ref), name
+
+
+@pytest.mark.parametrize("spherical", [False, True])
+def test_m2_from_C_intended_form(spherical):
+    """old-diagnose/diagnose.f90:359-380 restated as intended (the legacy lines read out of bounds): a sequential sum along r"""
+    nr, nz = 96, 40
+    rng = np.random.default_rng(9)
+    prof = H.profiles(nr, nz, 1 if spherical else 0, 0, (10.0, 60.0, 0.0, 1.5e4) if spherical else (1.0e3, 2.0e5, 0.0, 1.5e4))
+    rhoC = (1.0 + rng.random((nz - 1, nr))).astype(np.float32) * 1e-9
+    sin_t = prof["sin_table"] if spherical else None
+    want = np.zeros((nz - 1, nr - 1), np.float32)
+    H.oracle().orc_m2_from_C(rhoC, want, prof["ra"], prof["rcuva"], None if sin_t is None else sin_t.ctypes.data, nr, nz)
+    assert biteq(X.m2_from_C(rhoC, prof, sin_t), want)

@@ -12,5 +12,5 @@ The directory name is not a Python identifier; load it with the repo-root helper
 from .xee import (  # noqa: F401
     Ensemble, XeeError, lib, lib_path, device_count, profiles, cal_coe, do_elliptic, solve_elliptic,
     solver_coefficients, residual_norm, cal_eta, cal_uw, integrate_weight_B, cal_sum_Qeta, cal_wtheta, rhs_thermal,
-    rhs_from_B, diagnose_case, CaseRecord, FIELDS, BAROTROPIC, BAROCLINIC, quotient_selfcheck, theta_tendency, relative_theta, theta_anomaly_update,
+    rhs_from_B, diagnose_case, CaseRecord, FIELDS, BAROTROPIC, BAROCLINIC, quotient_selfcheck, m2_from_C, theta_tendency, relative_theta, theta_anomaly_update,
 )

@@ -10,6 +10,7 @@
 #include "../../include/xee.h"
 #include "xee_device.h"
 
+#include <cmath>
 #include <vector>
 
 #pragma clang fp contract(off)
@@ -247,9 +248,43 @@ __global__ __launch_bounds__(64) void k_relative_theta_cols(float* __restrict__ 
     }
 }
 
+// old-diagnose/diagnose.f90:359-380 (intended form): per row j a sequential sum along r; cube[i] = rcuva(i)**3.0 (host powf),
+// cube[0] = ((rcuva(2)-rcuva(1))/4)**3.0
+__global__ __launch_bounds__(64) void k_m2_from_C(const float* __restrict__ rhoC, float* __restrict__ m2, const float* __restrict__ ra,
+        const float* __restrict__ cube, const float* __restrict__ sin_table /* or nullptr */, int nr, int nz)
+{
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    if (j >= nz - 1) return;
+    float acc = cube[0] * rhoC[(size_t)j * nr] * (ra[1] - ra[0]) / 2.0f;
+    if (sin_table) acc = acc / ((sin_table[1] + 3.0f * sin_table[0]) / 4.0f);
+    m2[(size_t)j * (nr - 1)] = acc;
+    for (int i = 1; i <= nr - 2; ++i) {
+        float t = cube[i] * rhoC[(size_t)j * nr + i] * (ra[i + 1] - ra[i - 1]) / 2.0f;
+        if (sin_table) t = t / sin_table[i];
+        acc = acc + t;
+        m2[(size_t)j * (nr - 1) + i] = acc;
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int xee_m2_from_C(const float* rhoC_C, const float* ra, const float* rcuva, const float* sin_table, float* m2_B, int nr, int nz)
+{
+    if (!rhoC_C || !ra || !rcuva || !m2_B || nr < 3 || nz < 4) return record_failure(XEE_ERR_INVALID_ARGUMENT, "xee_m2_from_C: bad argument");
+    TRY(need_device());
+    std::vector<float> cube(nr);
+    cube[0] = powf((rcuva[1] - rcuva[0]) / 4.0f, 3.0f);                    // :361 (host libm, like the Fortran runtime)
+    for (int i = 1; i < nr; ++i) cube[i] = powf(rcuva[i], 3.0f);           // :365
+    DevBuf dC, dra, dcube, dsin, dM;
+    TRY(dC.put(rhoC_C, (size_t)nr * (nz - 1))); TRY(dra.put(ra, nr)); TRY(dcube.put(cube.data(), nr));
+    if (sin_table) TRY(dsin.put(sin_table, nr));
+    TRY(dM.put(nullptr, (size_t)(nr - 1) * (nz - 1)));
+    hipLaunchKernelGGL(k_m2_from_C, dim3((nz + 63) / 64), dim3(64), 0, 0, dC.p, dM.p, dra.p, dcube.p, sin_table ? dsin.p : nullptr, nr, nz);
+    TRY(finish("xee_m2_from_C"));
+    return dM.get(m2_B);
+}
 
 int xee_theta_tendency(const float* JJ_B, const float* rhoA_A, const float* w_A, const float* rhoB_C, const float* u_C,
                        float* dtheta_dt_B, int nr, int nz)

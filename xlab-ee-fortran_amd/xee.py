@@ -107,6 +107,7 @@ def lib():
     L.xee_ensemble_records.argtypes = [vp, C.c_void_p]
     L.xee_ensemble_timing.argtypes = [vp, C.POINTER(Timing)]
     L.xee_ensemble_time_sweeps.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.xee_m2_from_C.argtypes = [_f32p, _f32p, _f32p, C.c_void_p, _f32p, C.c_int, C.c_int]
     L.xee_theta_tendency.argtypes = [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int]
     L.xee_relative_theta.argtypes = [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int]
     L.xee_theta_anomaly_update.argtypes = [_f32p, C.c_float, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p,
@@ -276,6 +277,15 @@ def exchange_conversion(rpsi, rchi, rhoC, prof):
 
 
 # ---- Tier 2: device-resident ensemble ---------------------------------------------------------
+
+def m2_from_C(rhoC_C, prof, sin_table=None):
+    """old-diagnose/diagnose.f90:359-380 (intended form) -> m2 on B cells (nz-1, nr-1)."""
+    nzm, nr = rhoC_C.shape
+    out = np.zeros((nzm, nr - 1), np.float32)
+    st = None if sin_table is None else _a(sin_table).ctypes.data_as(C.c_void_p)
+    _chk(lib().xee_m2_from_C(_a(rhoC_C), prof["ra"], prof["rcuva"], st, out, nr, nzm + 1))
+    return out
+
 
 def theta_tendency(JJ_B, rhoA_A, w_A, rhoB_C, u_C):
     """old-diagnose/diagnose.f90:470-479 -> dtheta/dt on B cells (nz-1, nr-1)."""
