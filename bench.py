@@ -2,26 +2,43 @@
 """bench.py -- diagnosed cases/s of the elliptic-solve + EE-diagnostic hot path on N MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+For N>1 without a launcher (WORLD_SIZE unset) the script starts `python -m torch.distributed.run --nproc-per-node N`
+on itself as a CHILD process -- before anything touches the GPU -- relays rank 0's JSON line and exits with the
+child's status; under a launcher (the driver's form) it runs as one rank.
 
 A *step* is one pass of the hot path over this rank's batch of synthetic cases, inputs already
 resident in HBM:   f = -B  ->  solver coefficients (K1)  ->  cal_coe (K2)  ->  solve_elliptic
 (K3+K4, fixed-work protocol of SURVEY.md 8d: r1=1e-8, r2 off, alpha=1, max_iter=100,000, check
 every 100)  ->  cal_eta (K5)  ->  EE scalars (K8)  ->  gather of the 128-byte case records over
-RCCL when N>1.  Cases are independent, so ranks share nothing but that gather (weak scaling:
+RCCL when N>1 (xee_gather_scalars).  Cases are independent, so ranks share nothing but that gather (weak scaling:
 --members cases per GPU; 32 x 8 GPUs is the 256-member ensemble of BASELINE.json configs[2]).
 
-Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (the Jacobi sweep) with the
-ALGORITHMIC byte count of SURVEY.md 8(d) -- 48 B per interior point per iteration -- over the device
-time of the sweep launches, measured with HIP events on the stream they run on (inside libxee's
-solve driver, xee_timing_t.sweep_ms).  `cpu_baseline` times the reference's own solve_elliptic
-(oracle/_ref/libref_elliptic.so, built from the reference sources with amdflang -O2) -- or, if that
-file is absent, the oracle's reference-loop-order port -- on ONE host core for a bounded sample.
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel, the temporally blocked Jacobi sweep:
+  * it is VALU-issue bound, not HBM bound (profiles/r02): `bound` = "valu", `achieved` = the
+    reference formulation's 22 flop per interior point per iteration x the point-iterations the
+    sweep launches did / their device time (HIP events on the stream they run on, xee_timing_t.sweep_ms); `peak` =
+    the fp32 VALU issue rate of UNFUSED, UNPACKED operations, 256 CU x 4 SIMD x 16 lanes x 2.4 GHz = 39.3 Tflop/s
+    (bit parity forbids contracting the reference's separately rounded multiplies and adds into FMAs; the packed-FMA
+    spec figure, 157.3 TF, is quoted beside it as `peak_spec`);
+  * `traffic` = HBM bytes per launch from the committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this workload
+    (profiles/traffic.json), `hbm` = the byte view: SURVEY.md 8(d)'s algorithmic figure for a kernel that rebuilds
+    the stencil from its generating planes (20 B per point and iteration for BAROTROPIC, 24 B with B), once per
+    point and T-iteration launch as the compulsory bytes of a blocked pass, the real rate traffic / launch time
+    against the 8 TB/s peak, and the reference formulation's 48-B "effective" rate as a named side value.
+`cpu_baseline` times the reference's own solve_elliptic (oracle/_ref/libref_elliptic.so, built from the reference
+sources with amdflang -O2) -- or, if that file is absent, the oracle's reference-loop-order port -- on ONE host core
+for a bounded sample; `cpu_baseline_all_cores` runs one such process per available core concurrently.
+`check` ties the timed work to a golden: the md5 of member 0's psi and eta after the timed region (computed outside
+it) and whether they equal the reference's own output for that case (tests/golden/golden_hashes.json).
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -32,8 +49,12 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
-HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-BYTES_PER_POINT_ITER = 48.0  # 9 coe + f + psi read, psi' written
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+VALU_PEAK_TFLOPS = 39.3       # 256 CU x 4 SIMD x 16 lanes x 2.4 GHz: one unfused, unpacked fp32 op per lane and cycle
+VALU_SPEC_TFLOPS = 157.3      # MI355X_MICROARCH.md: vector fp32 spec (packed FMA: x2 x2)
+FLOP_PER_POINT_ITER = 22.0    # 9 mul + 8 add, 1 sub, 1 mul, 1 div, 1 neg, 1 add
+BYTES_48 = 48.0               # reference formulation (9 coe + f + psi read, psi' written)
+BYTES_RECOMPUTE = {"BAROTROPIC": 20.0, "BAROCLINIC": 24.0}   # stencil rebuilt from a, (b,) c
 
 
 def member_fields(nr, nz, m):
@@ -50,16 +71,17 @@ def member_fields(nr, nz, m):
     return one, B.astype(np.float32), one, np.zeros((nz, nr), np.float32), Q.astype(np.float32)
 
 
-def traffic_per_launch(kernel, nr, nz, members, T, operator="BAROTROPIC"):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/traffic.json, corrections documented in profiles/r01/pmc/README.md); None unless an
-    entry was measured for exactly this workload."""
+def traffic_entry(kernel, nr, nz, members, operator):
+    """The committed PMC record of the dominant kernel for exactly this workload (profiles/traffic.json, written
+    by tools/pmc_summarize.py from the rocprofv3 FETCH_SIZE / WRITE_SIZE / SQ passes, corrections as
+    MI355X_MICROARCH.md prescribes and calibrated in the same run); None when none was measured."""
     try:
-        ent = json.loads((ROOT / "profiles" / "traffic.json").read_text()).get(kernel)
+        ents = json.loads((ROOT / "profiles" / "traffic.json").read_text()).get("entries", [])
     except (OSError, ValueError):
         return None
-    if ent and (ent["nr"], ent["nz"], ent["members"], ent["T"], ent.get("operator", "BAROTROPIC")) == (nr, nz, members, T, operator):
-        return ent["bytes_per_launch"]
+    for e in ents:
+        if (e["short"], e["nr"], e["nz"], e["members"], e["operator"]) == (kernel, nr, nz, members, operator):
+            return e
     return None
 
 
@@ -89,6 +111,73 @@ def cpu_baseline(nr, nz, max_iter, sample_iters):
             "ms_per_iteration": per_iter * 1e3}
 
 
+def _cpu_child(nr, nz, max_iter, sample_iters):
+    """One baseline process: the reference prints "Elliptic Tools: ..." through the Fortran runtime's own buffer,
+    flushed at exit -- it must not land on the bench's stdout (ONE JSON line), so the result travels on stderr."""
+    code = ("import json, sys; sys.path.insert(0, %r); import bench; "
+            "r = bench.cpu_baseline(%d, %d, %d, %d); sys.stdout.flush(); "
+            "sys.stderr.write('XEE_CPU_BASELINE ' + json.dumps(r) + '\\n')" % (str(ROOT), nr, nz, max_iter, sample_iters))
+    return subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+
+
+def _cpu_result(p):
+    err = p.communicate()[1]
+    for line in err.splitlines():
+        if line.startswith("XEE_CPU_BASELINE "):
+            return json.loads(line[len("XEE_CPU_BASELINE "):])
+    raise SystemExit("cpu_baseline child failed:\n" + err[-2000:])
+
+
+def cpu_baselines(nr, nz, max_iter, sample_iters):
+    """(one-core record, all-core record): SURVEY.md 8(d)(ii) -- the reference on 1 core, then as `cores`
+    concurrent independent single-core processes (the reference is single-threaded; cases are independent)."""
+    one = _cpu_result(_cpu_child(nr, nz, max_iter, sample_iters))
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, int(os.environ.get("XEE_CPU_CORES", "16"))))   # the GPU box's CPU share for one GPU
+    n_it = max(20, sample_iters // 2)
+    t0 = time.perf_counter()
+    kids = [_cpu_child(nr, nz, max_iter, n_it) for _ in range(cores)]
+    recs = [_cpu_result(k) for k in kids]
+    wall = time.perf_counter() - t0
+    # aggregate rate from each process's own solve time (process start-up and the one-off input assembly excluded,
+    # as in the one-core figure); they ran concurrently, so contention for memory bandwidth is in those times
+    agg = sum(r["value"] for r in recs)
+    allc = {"value": agg, "unit": "cases/s", "cores": cores, "kind": one["kind"],
+            "sample": f"{cores} concurrent single-core processes, each solve_elliptic on one {nr}x{nz} case for {n_it} iterations "
+                      f"(mean {sum(r['ms_per_iteration'] for r in recs) / cores:.2f} ms/iteration per process; {wall:.1f} s wall "
+                      f"including start-up), scaled linearly to {max_iter} iterations",
+            "speedup_over_one_core": agg / one["value"]}
+    return one, allc
+
+
+def self_launch(args):
+    """--gpus N>1 without a launcher: run N ranks of this script as a child of torch.distributed.run.  Nothing in
+    this process has touched the GPU (no HIP call, no torch.cuda query), so spawning is safe."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, env=env)
+    line = None
+    for ln in p.stdout:
+        if ln.lstrip().startswith("{") and '"metric"' in ln:
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = p.wait()
+    if line:
+        print(line, flush=True)
+    elif rc == 0:
+        rc = 1
+    raise SystemExit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,6 +193,8 @@ def main():
                     help="ensemble (default: the bench line) | single (configs[1]: one case) | highres (configs[3]: one "
                          "4096x2048 case, 2,000 iterations) | baroclinic (the ensemble with the full-B operator)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     if args.workload == "single":
         args.members = 1
     elif args.workload == "highres":
@@ -124,7 +215,7 @@ def main():
         local_rank = int(os.environ["XEE_BENCH_DEVICE"])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available() or xee.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: libxee has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -137,6 +228,7 @@ def main():
     coll_dev = "cuda" if backend == "nccl" else "cpu"
 
     nr, nz, M = args.nr, args.nz, args.members
+    operator = "BAROCLINIC" if args.workload == "baroclinic" else "BAROTROPIC"
     prof = xee.profiles(nr, nz, 0, 0, (0.0, 1.0, 0.0, 1.0))
     ens = xee.Ensemble(nr, nz, M, device=local_rank)
     ens.set_profiles(prof)
@@ -150,7 +242,7 @@ def main():
 
     def step():
         ens.forcing_from_B()                   # A7
-        ens.assemble(xee.BAROCLINIC if args.workload == "baroclinic" else xee.BAROTROPIC)   # K1 + K2
+        ens.assemble(xee.BAROCLINIC if operator == "BAROCLINIC" else xee.BAROTROPIC)   # K1 + K2
         ens.solve(args.max_iter, 1e-8, -1.0, 1.0, check_step=100, converge_time=10, lost_rate=5)   # K3 + K4
         ens.cal_eta()                          # K5
         rec = ens.ee_scalars()                 # K8
@@ -186,11 +278,25 @@ def main():
     if rank == 0:
         cases = world * M * args.steps
         interior = (nr - 2) * (nz - 2)
-        alg_bytes = BYTES_PER_POINT_ITER * interior * M * iters        # this rank, all timed steps
-        achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
-        tb_T = int(os.environ.get("XEE_TB_T", "6"))
-        kernel = ("k_sweep_tb" if os.environ.get("XEE_NO_BASE4") else
-                  "k_sweep_tb4" if os.environ.get("XEE_NO_FASTQ") else "k_sweep_q") if tb_T > 1 else "k_sweep_stream"
+        sweep_s = sweep_ms * 1e-3
+        info = ens.sweep_info()
+        kernel, tb_T = info["kernel"], info["T"]
+        point_iters = float(interior) * M * iters                        # this rank, all timed steps
+        tflops = FLOP_PER_POINT_ITER * point_iters / sweep_s / 1e12 if sweep_s > 0 else 0.0
+        avg_launch_s = sweep_s / max(launches, 1)
+        ent = traffic_entry(kernel, nr, nz, M, operator)
+        traffic = ent["bytes_per_launch"] if ent else None
+        b_alg = BYTES_RECOMPUTE[operator]
+        hbm = {"algorithmic_bytes_per_point_iter": b_alg,
+               "compulsory_bytes_per_launch": b_alg * interior * M,       # one blocked pass touches every plane once
+               "compulsory_GBps": b_alg * interior * M / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0,
+               "effective_GBps": b_alg * point_iters / sweep_s / 1e9 if sweep_s > 0 else 0.0,
+               "effective_GBps_48B_reference_formulation": BYTES_48 * point_iters / sweep_s / 1e9 if sweep_s > 0 else 0.0,
+               "real_GBps": traffic / avg_launch_s / 1e9 if traffic and avg_launch_s > 0 else None,
+               "real_frac_of_peak": traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS if traffic and avg_launch_s > 0 else None,
+               "peak_GBps": HBM_PEAK_GBS,
+               "note": "temporal blocking: T iterations per pass over the planes, so the effective rates may exceed the HBM peak; "
+                       "real_* is measured traffic (PMC) over the launch time"}
         out = {
             "metric": "diagnosed cases/s (1024x512 r-z grid, SOR to 1e-8)",
             "value": cases / dt, "unit": "cases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -200,35 +306,41 @@ def main():
                                    + (" (x8 GPUs = the 256-member ensemble of configs[2])" if args.workload == "ensemble" else "")
                                    + f"; each case = configs[1]: K1+K2+solve_elliptic(r1=1e-8, r2 off, alpha=1, "
                                    f"max_iter={args.max_iter}, check every 100)+cal_eta+EE scalars; operator "
-                                   + ("BAROCLINIC (full B)" if args.workload == "baroclinic" else "BAROTROPIC (B=0)"),
+                                   + ("BAROCLINIC (full B)" if operator == "BAROCLINIC" else "BAROTROPIC (B=0)"),
                        "nr": nr, "nz": nz, "members_per_gpu": M, "max_iter": args.max_iter,
                        "solver": "damped Jacobi, bit-identical to the reference (SURVEY.md finding 1)",
                        "parallelism": f"ensemble-dp{world}"},
             "iterations_per_s": world * M * iters / dt,
             "point_updates_per_s": world * M * iters * interior / dt,
             "all_cases_ran_to_max_iter": bool(len(rec) == world * M and np.all(rec["iters"] == args.max_iter)),
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_per_launch(kernel, nr, nz, M, tb_T,
-                                                                                "BAROCLINIC" if args.workload == "baroclinic" else "BAROTROPIC"),
-                         "kernel": f"{kernel} (damped-Jacobi sweep, {tb_T} iteration(s) per launch; temporal blocking "
-                                   "makes the effective rate exceed the HBM peak: traffic << algorithmic bytes)",
-                         "algorithmic_bytes_per_launch": alg_bytes / max(launches, 1),
-                         "avg_launch_us": sweep_ms * 1e3 / max(launches, 1), "launches": launches},
+            "roofline": {"bound": "valu", "achieved": tflops, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tflops / VALU_PEAK_TFLOPS, "traffic": traffic,
+                         "peak_spec": VALU_SPEC_TFLOPS, "frac_of_spec": tflops / VALU_SPEC_TFLOPS,
+                         "flop_per_point_iter": FLOP_PER_POINT_ITER,
+                         "kernel": f"{info['name']} (damped-Jacobi sweep, {tb_T} iteration(s) per launch, tile {info['tile']})",
+                         "avg_launch_us": avg_launch_s * 1e6, "launches": launches,
+                         "point_iterations_per_launch": point_iters / max(launches, 1),
+                         "valu_insts_per_launch": ent.get("SQ_INSTS_VALU") if ent else None,
+                         "hbm": hbm},
         }
+        # tie the timed work to a golden (outside the timed region): member 0 of rank 0
+        psi0 = ens.download("PSI", 0, 1)[0]
+        eta0 = ens.download("ETA", 0, 1)[0]
+        chk = {"member0_psi_md5": hashlib.md5(psi0.tobytes()).hexdigest(), "member0_eta_md5": hashlib.md5(eta0.tobytes()).hexdigest(),
+               "golden": None, "matches_golden": None}
+        try:
+            gh = json.loads((ROOT / "tests" / "golden" / "golden_hashes.json").read_text())
+            key = f"bench_m0{'_baroclinic' if operator == 'BAROCLINIC' else ''}_{args.max_iter}"
+            if (nr, nz) == (1024, 512) and key in gh:
+                g = gh[key]["md5"]
+                tag = "BAROCLINIC" if operator == "BAROCLINIC" else "BAROTROPIC"
+                chk["golden"] = f"tests/golden/golden_hashes.json:{key} (the reference program's own output)"
+                chk["matches_golden"] = bool(g[f"rchi-[{tag}]-O.bin"] == chk["member0_psi_md5"] and g[f"eta-[{tag}]-A.bin"] == chk["member0_eta_md5"])
+        except (OSError, ValueError, KeyError):
+            pass
+        out["check"] = chk
         if world == 1 and not args.no_cpu_baseline:
-            # in a child process: the reference prints "Elliptic Tools: ..." through the Fortran runtime's own
-            # buffer, which is flushed at exit -- it must not land on this process's stdout (ONE JSON line)
-            import subprocess
-            code = ("import json, sys; sys.path.insert(0, %r); import bench; "
-                    "r = bench.cpu_baseline(%d, %d, %d, %d); sys.stdout.flush(); "
-                    "sys.stderr.write('XEE_CPU_BASELINE ' + json.dumps(r) + '\\n')"
-                    % (str(ROOT), nr, nz, args.max_iter, args.cpu_sample_iters))
-            p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
-            for line in p.stderr.splitlines():
-                if line.startswith("XEE_CPU_BASELINE "):
-                    out["cpu_baseline"] = json.loads(line[len("XEE_CPU_BASELINE "):])
-            if "cpu_baseline" not in out:
-                raise SystemExit("cpu_baseline child failed:\n" + p.stderr[-2000:])
+            out["cpu_baseline"], out["cpu_baseline_all_cores"] = cpu_baselines(nr, nz, args.max_iter, args.cpu_sample_iters)
         print(json.dumps(out), flush=True)
     ens.close()
     if world > 1:

@@ -51,6 +51,23 @@ int         xee_version(void);
 const char *xee_last_error(void);          /* text of the last failure on this thread */
 int         xee_device_count(int *count);  /* number of visible HIP devices (0 is not an error) */
 
+/* Run-time options (integers, by name).  The library reads NO environment variables.  Defaults are process-wide
+ * and are copied into every ensemble at creation (the Tier-1 entry points create theirs internally);
+ * xee_ensemble_set_option changes one ensemble.  Every combination gives bit-identical results -- the options
+ * choose between implementations of the same arithmetic (tests run them against each other and the oracle):
+ *   "tb_T"             iterations per temporally blocked sweep launch, 1..16 (6); 1 = the streaming kernel
+ *   "kernel"           0 auto | 1 nine coefficient planes (k_sweep_tb) | 2 generating planes with the IEEE
+ *                      division (k_sweep_tb4) | 3 generating planes, hoisted reciprocal (k_sweep_q; auto's choice
+ *                      whenever xee_ensemble_assemble / xee_cal_coe built the planes)
+ *   "q_exact_only"     1: k_sweep_q runs its exact (fallback) body on every tile
+ *   "elision"          0: k_sweep_tb loads coefficient planes even when they are uniform over the batch (1)
+ *   "tile"             NW*100+R: waves x rows per lane of a blocked tile, 0 = the kernel's default
+ *   "sync_checks"      1: residual checks synchronous instead of pipelined behind the sweeps (0)
+ *   "exact_sum_serial" 1: order-exact sums by a single-lane walk instead of the parallel algorithm (0)
+ * Unknown keys and out-of-range values return XEE_ERR_INVALID_ARGUMENT. */
+int xee_set_default_option(const char *key, int value);
+int xee_reset_default_options(void);
+
 /* ---------------------------------------------------------------------------------------------
  * Tier 1 -- drop-in replacements, host arrays in / host arrays out.
  * ------------------------------------------------------------------------------------------- */
@@ -235,6 +252,9 @@ int xee_ensemble_destroy(xee_ensemble_t *ens);
 /* run on a caller-provided hipStream_t (e.g. torch's current stream); NULL = the ensemble's own */
 int xee_ensemble_set_stream(xee_ensemble_t *ens, void *hip_stream);
 int xee_ensemble_set_case_ids(xee_ensemble_t *ens, int first_case_id);
+int xee_ensemble_set_option(xee_ensemble_t *ens, const char *key, int value);
+/* which sweep kernel the last solve launched (name, iterations per launch, tile extent in points) */
+int xee_ensemble_sweep_info(xee_ensemble_t *ens, char *name, int name_len, int *T, int *tile_w, int *tile_h);
 /* A13 profiles are host-side work (glibc powf/cosf, initialize-variables.f90:44-67); hand them in */
 int xee_ensemble_set_profiles(xee_ensemble_t *ens, const float *ra, const float *za,
                               const float *rcuva, const float *rho, const float *exner,

@@ -22,3 +22,16 @@ def pytest_configure(config):
 def golden_hashes():
     import json
     return json.loads((ROOT / "tests" / "golden" / "golden_hashes.json").read_text())
+
+
+@pytest.fixture(autouse=True)
+def _reset_library_options():
+    """Run-time options set through xee.set_default_option are process-wide: put them back after every test."""
+    yield
+    try:
+        import xee_pkg
+        xee = xee_pkg.load()
+        if xee.lib_path().exists():
+            xee.reset_default_options()
+    except Exception:
+        pass

@@ -43,7 +43,9 @@ def run(name, A, B, Cc, bc, forcing=None, keep=True, **cfg):
 
 def main():
     big = "--big" in sys.argv
-    hashes = {}
+    old = OUT / "golden_hashes.json"
+    hashes = json.loads(old.read_text()) if old.exists() else {}     # keep what this run does not regenerate
+                                                                    # (--big cases, make_golden_deep.py's anchors)
     # 1. plumbing case P: test1 formula at 128x64, test1 criteria -> 6,300 iterations
     A, B, Cc, bc = H.test1_inputs(128, 64)
     hashes["p128x64_test1"] = run("p128x64_test1", A, B, Cc, bc, r1=5e-3, r2=5e-3, max_iter=100000, alpha=1.0)
@@ -81,13 +83,6 @@ def main():
         hashes["m1024x512_20000"] = run("m1024x512_20000", A, B, Cc, bc, keep=False, r1=1e-8, r2=-1.0, max_iter=20000, alpha=1.0)
         A, B, Cc, bc = H.test1_inputs(4096, 2048)
         hashes["l4096x2048_100"] = run("l4096x2048_100", A, B, Cc, bc, keep=False, r1=1e-8, r2=-1.0, max_iter=100, alpha=1.0)
-    else:
-        old = OUT / "golden_hashes.json"
-        if old.exists():
-            prev = json.loads(old.read_text())
-            for k in ("m1024x512_500", "m1024x512_20000", "l4096x2048_100"):
-                if k in prev:
-                    hashes[k] = prev[k]
     (OUT / "golden_hashes.json").write_text(json.dumps(hashes, indent=1, sort_keys=True) + "\n")
 
 

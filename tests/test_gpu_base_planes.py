@@ -19,15 +19,15 @@ def biteq(a, b):
 
 @pytest.mark.parametrize("variant", ["BAROTROPIC", "BAROCLINIC"])
 @pytest.mark.parametrize("nr,nz,iters,T", [(200, 120, 311, 6), (64, 48, 250, 8), (1024, 512, 203, 6), (130, 300, 301, 3), (97, 67, 199, 13)])
-def test_generating_planes_path_is_bit_identical(variant, nr, nz, iters, T, monkeypatch):
-    monkeypatch.setenv("XEE_TB_T", str(T))
+def test_generating_planes_path_is_bit_identical(variant, nr, nz, iters, T):
     A, B, Cc, bc = H.rich_inputs(nr, nz, seed=T + nr)
     cfg = dict(mode=("DYNAMIC_EFFICIENCY", "CYLINDRICAL", "DENSITY_NORMAL", variant),
                domain=(0.0, 2.0e5, 0.0, 1.5e4), r1=1e-8, r2=-1.0, max_iter=iters, alpha=0.9)
-    monkeypatch.delenv("XEE_NO_BASE4", raising=False)
-    got4 = xee.diagnose_case(A, B, Cc, bc, **cfg)[variant]
-    monkeypatch.setenv("XEE_NO_BASE4", "1")
-    got9 = xee.diagnose_case(A, B, Cc, bc, **cfg)[variant]
+    got4 = xee.diagnose_case(A, B, Cc, bc, options={"tb_T": T}, **cfg)[variant]
+    got9 = xee.diagnose_case(A, B, Cc, bc, options={"tb_T": T, "kernel": 1}, **cfg)[variant]
+    gotx = xee.diagnose_case(A, B, Cc, bc, options={"tb_T": T, "kernel": 2}, **cfg)[variant]
+    assert got4["sweep"]["kernel"] == "k_sweep_q" and got9["sweep"]["kernel"] == "k_sweep_tb" and gotx["sweep"]["kernel"] == "k_sweep_tb4"
+    assert biteq(gotx["psi"][0], want_psi := H.diagnose_case(A, B, Cc, bc, **cfg)[variant]["psi"])
     want = H.diagnose_case(A, B, Cc, bc, **cfg)[variant]
     assert biteq(got4["psi"][0], want["psi"]) and biteq(got9["psi"][0], want["psi"])
     assert got4["r1"][0].tobytes() == want["r1"].tobytes() == got9["r1"][0].tobytes()

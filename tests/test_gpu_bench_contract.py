@@ -26,11 +26,36 @@ def test_bench_prints_one_json_line_with_required_keys():
     assert d["unit"] == "cases/s" and d["n_gpus"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and "traffic" in r
+    # the blocked sweep is VALU-issue bound: priced in flop/s against the unfused fp32 issue peak; the byte view
+    # (algorithmic, compulsory and measured-traffic rates against the 8 TB/s HBM peak) sits beside it
+    assert r["bound"] == "valu" and r["unit"] == "TFLOP/s" and r["peak"] == 39.3 and r["peak_spec"] == 157.3
+    assert 0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and "traffic" in r
+    h = r["hbm"]
+    assert h["peak_GBps"] == 8000.0 and h["algorithmic_bytes_per_point_iter"] == 20.0 and h["compulsory_GBps"] > 0
+    assert h["real_frac_of_peak"] is None or 0 < h["real_frac_of_peak"] <= 1.0
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["value"] > 0 and "sample" in c
+    ca = d["cpu_baseline_all_cores"]
+    assert ca["cores"] >= 1 and ca["value"] >= 0.5 * c["value"] and ca["kind"] == c["kind"]
     assert d["all_cases_ran_to_max_iter"] is True and d["value"] > 0
+    k = d["check"]
+    assert len(k["member0_psi_md5"]) == 32 and len(k["member0_eta_md5"]) == 32 and k["matches_golden"] is None   # (no golden at 128x64)
+
+
+def test_bench_gpus2_as_a_plain_command_self_launches():
+    """`python bench.py --gpus 2` with no launcher around it starts its own ranks as a child of torch.distributed.run
+    (before touching the GPU) and relays the one JSON line; rehearsed on one card over gloo."""
+    import os
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(XEE_BENCH_BACKEND="gloo", XEE_BENCH_DEVICE="0")
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--members", "2", "--nr", "128", "--nz", "64",
+                        "--max-iter", "200", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["all_cases_ran_to_max_iter"] is True and d["config"]["parallelism"] == "ensemble-dp2"
 
 
 def test_bench_two_ranks_rehearsal_over_gloo():

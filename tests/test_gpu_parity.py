@@ -220,15 +220,15 @@ def test_ee_scalars_ensemble():
 
 @pytest.mark.parametrize("T", [2, 3, 5, 8, 13, 16])
 @pytest.mark.parametrize("nr,nz,iters", [(200, 120, 437), (64, 48, 250), (1024, 512, 203), (130, 300, 301)])
-def test_temporal_blocking_is_bit_identical(T, nr, nz, iters, monkeypatch):
+def test_temporal_blocking_is_bit_identical(T, nr, nz, iters):
     """T iterations per launch (overlapped tiles, register-resident coefficients) must reproduce the
     oracle bit for bit for every T, incl. tiles cut by the domain edge, ragged last tiles and a
     check iteration (multiple of 100) that falls inside a launch."""
-    monkeypatch.setenv("XEE_TB_T", str(T))
     A, B, Cc, bc = H.rich_inputs(nr, nz, seed=T + nr)
     cfg = dict(mode=("DYNAMIC_EFFICIENCY", "CYLINDRICAL", "DENSITY_NORMAL", "BAROCLINIC"),
                domain=(0.0, 2.0e5, 0.0, 1.5e4), r1=1e-8, r2=-1.0, max_iter=iters, alpha=0.9)
-    got = xee.diagnose_case(A, B, Cc, bc, **cfg)["BAROCLINIC"]
+    got = xee.diagnose_case(A, B, Cc, bc, options={"tb_T": T}, **cfg)["BAROCLINIC"]
+    assert got["sweep"]["T"] == T
     want = H.diagnose_case(A, B, Cc, bc, **cfg)["BAROCLINIC"]
     assert int(got["iters"][0]) == want["iters"] == iters
     assert biteq(got["psi"][0], want["psi"])
@@ -289,13 +289,12 @@ def test_exact_residual_norm_adversarial(name):
         assert slow < 0.02 * nchunks + 40, (slow, nchunks)      # the fast path must actually be taken
 
 
-def test_exact_norm_equals_serial_walk_in_solver(monkeypatch):
+def test_exact_norm_equals_serial_walk_in_solver():
     """Same solve with the single-lane reference-order walk and with the parallel algorithm."""
     A, B, Cc, bc = H.rich_inputs(64, 48, seed=13)
     cfg = dict(r1=1e-6, r2=2e-3, max_iter=100000, alpha=1.0, domain=(0.0, 2.0e5, 0.0, 1.5e4))
     a = xee.diagnose_case(A, B, Cc, bc, **cfg)["BAROTROPIC"]
-    monkeypatch.setenv("XEE_EXACT_SUM", "serial")
-    b = xee.diagnose_case(A, B, Cc, bc, **cfg)["BAROTROPIC"]
+    b = xee.diagnose_case(A, B, Cc, bc, options={"exact_sum_serial": 1}, **cfg)["BAROTROPIC"]
     assert int(a["iters"][0]) == int(b["iters"][0]) and biteq(a["psi"], b["psi"])
     assert a["r1"].tobytes() == b["r1"].tobytes() and a["r2"].tobytes() == b["r2"].tobytes()
     assert int(a["err"][0]) == 0, "this case is meant to converge before max_iter"
@@ -321,10 +320,12 @@ def test_uniform_plane_elision_nonzero_constants():
     assert biteq(got[0], want[0]) and got[3].tobytes() == want[3].tobytes()
 
 
-def test_elision_on_off_same_bits(monkeypatch):
+def test_elision_on_off_same_bits():
     A, B, Cc, bc = H.test1_inputs(200, 200)
     cfg = dict(r1=1e-8, r2=-1.0, max_iter=400, alpha=1.0)
-    a = xee.diagnose_case(A, B, Cc, bc, **cfg)["BAROTROPIC"]
-    monkeypatch.setenv("XEE_NO_ELISION", "1")
-    b = xee.diagnose_case(A, B, Cc, bc, **cfg)["BAROTROPIC"]
+    a = xee.diagnose_case(A, B, Cc, bc, options={"kernel": 1}, **cfg)["BAROTROPIC"]       # nine planes, uniform ones elided
+    b = xee.diagnose_case(A, B, Cc, bc, options={"kernel": 1, "elision": 0}, **cfg)["BAROTROPIC"]
+    want = H.diagnose_case(A, B, Cc, bc, **cfg)["BAROTROPIC"]
+    assert a["sweep"]["name"] == "k_sweep_tb<elided>" and b["sweep"]["name"] == "k_sweep_tb"
+    assert biteq(a["psi"][0], want["psi"])
     assert biteq(a["psi"], b["psi"]) and a["r1"].tobytes() == b["r1"].tobytes()

@@ -1,6 +1,6 @@
 """The residual checks run pipelined behind the sweeps by default (the check of iteration k is evaluated
 while the next block already iterates; results of members that stop come from a snapshot).  It must give
-exactly what the synchronous driver (XEE_SYNC_CHECKS=1) and the oracle give -- iteration counts, fields,
+exactly what the synchronous driver (option "sync_checks") and the oracle give -- iteration counts, fields,
 residues -- for members stopping at different checks, at max_iter on and off a check boundary."""
 import numpy as np
 import pytest
@@ -18,22 +18,18 @@ def biteq(a, b):
     return a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
-def run(A, B, Cc, bc, cfg, sync, monkeypatch):
-    if sync:
-        monkeypatch.setenv("XEE_SYNC_CHECKS", "1")
-    else:
-        monkeypatch.delenv("XEE_SYNC_CHECKS", raising=False)
-    return xee.diagnose_case(A, B, Cc, bc, **cfg)["BAROTROPIC"]
+def run(A, B, Cc, bc, cfg, sync):
+    return xee.diagnose_case(A, B, Cc, bc, options={"sync_checks": 1 if sync else 0}, **cfg)["BAROTROPIC"]
 
 
 @pytest.mark.parametrize("max_iter", [20000, 437, 300, 57])
-def test_pipelined_equals_synchronous_and_oracle(max_iter, monkeypatch):
+def test_pipelined_equals_synchronous_and_oracle(max_iter):
     nr, nz, M = 96, 64, 7
     ins = [H.member_inputs(nr, nz, m) for m in range(M)]
     A, B, Cc, bc = (np.stack([x[k] for x in ins]) for k in range(4))
     cfg = dict(r1=2e-4, r2=5e-3, max_iter=max_iter, alpha=1.0)
-    a = run(A, B, Cc, bc, cfg, False, monkeypatch)
-    b = run(A, B, Cc, bc, cfg, True, monkeypatch)
+    a = run(A, B, Cc, bc, cfg, False)
+    b = run(A, B, Cc, bc, cfg, True)
     assert np.array_equal(a["iters"], b["iters"]) and np.array_equal(a["err"], b["err"])
     assert biteq(a["psi"], b["psi"]) and biteq(a["eta"], b["eta"])
     assert a["r1"].tobytes() == b["r1"].tobytes() and a["r2"].tobytes() == b["r2"].tobytes()
@@ -46,7 +42,7 @@ def test_pipelined_equals_synchronous_and_oracle(max_iter, monkeypatch):
         assert len(set(int(v) for v in a["iters"])) > 1 and int(a["iters"].max()) < max_iter
 
 
-def test_pipelined_other_check_steps(monkeypatch):
+def test_pipelined_other_check_steps():
     """check_step that is not a multiple of the blocked launch length, tiny converge_time."""
     nr, nz = 80, 56
     A, B, Cc, bc = H.rich_inputs(nr, nz, seed=4)
@@ -56,8 +52,46 @@ def test_pipelined_other_check_steps(monkeypatch):
     f = (-B).astype(np.float32)
     for cs, ct, mi in ((7, 3, 5000), (25, 2, 1013), (1, 4, 40)):
         want = H.solve(bc, coe, f, mi, 1e-6, 5e-2, 1.0, check_step=cs, converge_time=ct)
-        monkeypatch.delenv("XEE_SYNC_CHECKS", raising=False)
         got = xee.solve_elliptic(bc, coe, f, mi, 1e-6, 5e-2, 1.0, check_step=cs, converge_time=ct)
         assert got[1] == want[1] and got[2] == want[2], (cs, ct, mi, got[1:3], want[1:3])
         assert biteq(got[0], want[0])
         assert got[3].tobytes() == want[3].tobytes() and got[4].tobytes() == want[4].tobytes()
+
+
+def _oracle_residual(A, B, Cc, bc, cfg, c):
+    """residual plane of check iteration c: do_elliptic(psi_{c-1}) - f on the interior (elliptic_tools.f90:189-190)"""
+    import ctypes as C
+    o = H.diagnose_case(A, B, Cc, bc, **dict(cfg, max_iter=c - 1))["BAROTROPIC"]
+    assert o["iters"] == c - 1, "the case must not stop before the check whose residual is wanted"
+    nz, nr = A.shape
+    out = np.zeros((nz, nr), np.float32)
+    err = C.c_int(0)
+    H.oracle().orc_do_elliptic(o["psi"], o["coe"], out, nr, nz, C.byref(err))
+    f = (-B).astype(np.float32)
+    out[1:-1, 1:-1] = out[1:-1, 1:-1] - f[1:-1, 1:-1]
+    return out
+
+
+@pytest.mark.parametrize("sync", [0, 1])
+@pytest.mark.parametrize("max_iter", [200, 300, 437])
+def test_residual_field_is_the_last_checks_plane(sync, max_iter):
+    """XEE_F_RESIDUAL after a solve = the residual plane of each member's last check, in both drivers (the pipelined
+    one alternates two planes): members that stop at different checks, and a cap on / off a check boundary."""
+    nr, nz, M = 96, 64, 5
+    ins = [H.member_inputs(nr, nz, m) for m in range(M)]
+    A, B, Cc, bc = (np.stack([x[k] for x in ins]) for k in range(4))
+    for crit in (dict(r1=1e-8, r2=-1.0), dict(r1=2e-4, r2=5e-3)):
+        cfg = dict(max_iter=max_iter if crit["r2"] < 0 else 20000, alpha=1.0, **crit)
+        with xee.Ensemble(nr, nz, M) as e:
+            e.set_option("sync_checks", sync)
+            e.set_profiles(xee.profiles(nr, nz))
+            for name, arr in (("A", A), ("B", B), ("C", Cc), ("BC_INIT", bc)):
+                e.upload(name, arr)
+            e.forcing_from_B()
+            e.assemble(xee.BAROTROPIC)
+            rec = e.solve(cfg["max_iter"], cfg["r1"], cfg["r2"], cfg["alpha"])
+            res = e.download("RESIDUAL")
+        for m in (0, 2, 4):
+            c = (int(rec["iters"][m]) // 100) * 100
+            want = _oracle_residual(A[m], B[m], Cc[m], bc[m], cfg, c)
+            assert biteq(res[m][1:-1, 1:-1], want[1:-1, 1:-1]), (sync, max_iter, crit, m, int(rec["iters"][m]))

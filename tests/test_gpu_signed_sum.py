@@ -68,11 +68,8 @@ def test_signed_sum_with_metric_factors_and_serial_switch():
     eta = rng.standard_normal((nz, nr - 1)).astype(np.float32)
     assert xee.integrate_weight_B(Q, prof).tobytes() == H.integrate_weight_B(Q, prof).tobytes()
     assert xee.cal_sum_Qeta(Q, eta, prof).tobytes() == H.cal_sum_Qeta(Q, eta, prof).tobytes()
-    # the single-lane walk (XEE_EXACT_SUM=serial) gives the same bits
-    code = ("import sys; sys.path.insert(0, 'tests'); import numpy as np, orchelp as H, xee_pkg; xee = xee_pkg.load(); "
-            "rng = np.random.default_rng(3); nr, nz = 257, 129; prof = H.profiles(nr, nz, 0, 0, (1.0e3, 2.0e5, 0.0, 1.5e4)); "
-            "Q = rng.standard_normal((nz - 1, nr - 1)).astype(np.float32); print('SUM', xee.integrate_weight_B(Q, prof).tobytes().hex())")
-    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, XEE_EXACT_SUM="serial"),
-                         capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0, out.stderr[-1500:]
-    assert f"SUM {xee.integrate_weight_B(Q, prof).tobytes().hex()}" in out.stdout
+    # the single-lane walk (option "exact_sum_serial") gives the same bits
+    par = xee.integrate_weight_B(Q, prof)
+    xee.set_default_option("exact_sum_serial", 1)          # (conftest resets the defaults after the test)
+    assert xee.integrate_weight_B(Q, prof).tobytes() == par.tobytes()
+    assert xee.cal_sum_Qeta(Q, eta, prof).tobytes() == H.cal_sum_Qeta(Q, eta, prof).tobytes()

@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 counter CSVs of tools/profile_round.sh into profiles/<round>/pmc_summary.json and
+profiles/traffic.json (the per-launch HBM bytes bench.py quotes as roofline.traffic).
+
+    python tools/pmc_summarize.py gpurun_out/<tag> profiles/<round>
+
+Layout read:  <tag>/pmc/<workload>/<pass>/**/*counter_collection.csv   pass in {fetch, write, sq1, sq2}
+HBM bytes follow MI355X_MICROARCH.md (HBM / rocprofv3 PMC sections): FETCH_SIZE and WRITE_SIZE in separate
+passes, KiB per dispatch; on gfx950 FETCH_SIZE under-reports coalesced reads by a width-dependent factor, which
+is CALIBRATED IN THE SAME RUN on two kernels of known byte count: k_negate (16 B/lane: the guide's exact 1/2) and
+k_cal_eta (4 B/lane).  The sweep's factor is the one of its load width (LOAD_WIDTH below).
+"""
+import csv
+import glob
+import json
+import sys
+from collections import defaultdict
+from pathlib import Path
+
+SHAPES = {"ensemble": (1024, 512, 32, "BAROTROPIC"), "baroclinic": (1024, 512, 32, "BAROCLINIC"),
+          "single": (1024, 512, 1, "BAROTROPIC"), "highres": (4096, 2048, 1, "BAROTROPIC")}
+# bytes per lane of the dominant kernel's global loads (decides which calibration applies)
+LOAD_WIDTH = {"k_sweep_q": 4, "k_sweep_tb4": 4, "k_sweep_tb": 4, "k_sweep_stream": 16, "k_sweep_p": 8}
+
+
+def read_pass(d):
+    """-> {kernel_name: {counter: [values per dispatch]}}, {kernel_name: meta}"""
+    vals = defaultdict(lambda: defaultdict(list))
+    meta = {}
+    for fn in glob.glob(str(d / "**" / "*counter_collection.csv"), recursive=True):
+        with open(fn, newline="") as f:
+            for row in csv.DictReader(f):
+                k = row["Kernel_Name"]
+                vals[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+                meta[k] = {"grid": int(row["Grid_Size"]), "wg": int(row["Workgroup_Size"]), "vgpr": int(row["VGPR_Count"]),
+                           "agpr": int(row["Accum_VGPR_Count"]), "lds": int(row["LDS_Block_Size"]), "scratch": int(row["Scratch_Size"])}
+    return vals, meta
+
+
+def short(name):
+    for k in ("k_sweep_q", "k_sweep_p", "k_sweep_tb4", "k_sweep_tb", "k_sweep_stream"):
+        if k + "<" in name:
+            return k
+    return None
+
+
+def main():
+    src, dst = Path(sys.argv[1]), Path(sys.argv[2])
+    dst.mkdir(parents=True, exist_ok=True)
+    summary, entries = {}, []
+    for wl, (nr, nz, M, op) in SHAPES.items():
+        base = src / "pmc" / wl
+        if not base.exists():
+            continue
+        per = {}
+        for p in ("fetch", "write", "sq1", "sq2"):
+            if (base / p).exists():
+                per[p] = read_pass(base / p)
+        if "fetch" not in per:
+            continue
+        fv, fmeta = per["fetch"]
+        # dominant sweep kernel = the sweep instantiation with the most dispatches
+        sweeps = [(len(v["FETCH_SIZE"]), k) for k, v in fv.items() if short(k)]
+        if not sweeps:
+            continue
+        _, kname = max(sweeps)
+        mean = lambda xs: sum(xs) / len(xs)
+        plane_kib = ((nr + 63) // 64 * 64) * nz * 4 / 1024.0 * M
+        cal = {}
+        for k, v in fv.items():
+            if "k_negate" in k:
+                cal["x16"] = mean(v["FETCH_SIZE"]) / plane_kib
+            if "k_cal_eta" in k:
+                cal["x4"] = mean(v["FETCH_SIZE"]) / (nr * nz * 4 / 1024.0 * M)
+        width = LOAD_WIDTH.get(short(kname), 4)
+        corr = cal.get("x16", 0.5) if width == 16 else cal.get("x4", 0.735) if width == 4 else None
+        if corr is None:            # 8 B/lane: not separately calibrated, bracket between the two
+            corr = 0.5 * (cal.get("x16", 0.5) + cal.get("x4", 0.735))
+        fetch = mean(fv[kname]["FETCH_SIZE"])
+        rec = {"workload": wl, "kernel": kname, "short": short(kname), "nr": nr, "nz": nz, "members": M, "operator": op,
+               "dispatches": len(fv[kname]["FETCH_SIZE"]), **fmeta[kname],
+               "FETCH_SIZE_kib": fetch, "fetch_calibration": cal, "fetch_correction": corr, "load_width_B": width}
+        if "write" in per and kname in per["write"][0]:
+            rec["WRITE_SIZE_kib"] = mean(per["write"][0][kname]["WRITE_SIZE"])
+            rec["bytes_per_launch"] = (fetch / corr + rec["WRITE_SIZE_kib"]) * 1024.0
+        for p in ("sq1", "sq2"):
+            if p in per and kname in per[p][0]:
+                for c, xs in per[p][0][kname].items():
+                    rec[c] = mean(xs)
+        summary[wl] = rec
+        if "bytes_per_launch" in rec:
+            entries.append({k: rec[k] for k in ("workload", "short", "kernel", "nr", "nz", "members", "operator", "FETCH_SIZE_kib",
+                                                "WRITE_SIZE_kib", "fetch_correction", "bytes_per_launch")}
+                           | {c: rec[c] for c in rec if c.startswith("SQ_")})
+    (dst / "pmc_summary.json").write_text(json.dumps(summary, indent=1) + "\n")
+    if entries:
+        tj = dst.parent / "traffic.json"
+        (tj).write_text(json.dumps({"_comment": "per-launch HBM bytes and SQ counters of the dominant sweep kernel, from the rocprofv3 PMC passes "
+                                    f"summarised in {dst.name}/pmc_summary.json (tools/pmc_summarize.py); bench.py quotes the entry of its workload",
+                                    "round": dst.name, "entries": entries}, indent=1) + "\n")
+    print(json.dumps(summary, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,14 +1,33 @@
 #!/bin/bash
-# end-of-round measurement pass on the GPU box: kernel-trace stats of the default bench, then the two PMC passes
-# (separate runs, no trace domains mixed with --pmc).  Usage: tools/profile_round.sh <tag>
+# Measurement pass on the GPU box.  Usage: tools/profile_round.sh <tag> [workloads...]
+#   1. kernel-trace stats of the default bench (rocprofv3 --kernel-trace --stats)
+#   2. per workload: FETCH_SIZE pass, WRITE_SIZE pass (separate: TCC has 4 slots, the two need 3 + 2) and two SQ
+#      passes on the PRODUCTION kernels (tools/pmc_workload.py) -- counters only, no trace domains besides
+#      --kernel-trace (gpurun refuses --pmc mixed with sys/hip/hsa traces)
+# Everything lands in gpurun_out/<tag>/; tools/pmc_summarize.py condenses it into profiles/<round>/.
 set -e
-tag=$1
+tag=$1; shift
+wls=${@:-ensemble baroclinic single highres}
 root=$(pwd)
 out=$root/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $root/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $out/bench_under_rocprof.json 2> $out/bench_under_rocprof.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 $root/tools/pmc_case.py 1024 512 32 > $out/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 $root/tools/pmc_case.py 1024 512 32 > $out/pmc_write.log 2>&1
+echo "stats done"
+SQ1="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAIT_ANY"
+SQ2="SQ_WAVES SQ_INSTS_SALU SQ_INSTS_VMEM SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_BUSY_CU_CYCLES"
+for wl in $wls; do
+  d=$out/pmc/$wl
+  mkdir -p $d
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $d/fetch -- python3 $root/tools/pmc_workload.py $wl > $d/fetch.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $d/write -- python3 $root/tools/pmc_workload.py $wl > $d/write.log 2>&1
+  rocprofv3 --kernel-trace --pmc $SQ1 --output-format csv -d $d/sq1 -- python3 $root/tools/pmc_workload.py $wl > $d/sq1.log 2>&1 || echo "sq1 pass failed for $wl (see $d/sq1.log)"
+  rocprofv3 --kernel-trace --pmc $SQ2 --output-format csv -d $d/sq2 -- python3 $root/tools/pmc_workload.py $wl > $d/sq2.log 2>&1 || echo "sq2 pass failed for $wl (see $d/sq2.log)"
+  echo "pmc $wl done"
+done
 cd $root
+# the raw per-dispatch CSVs are large: keep only what the summary needs (the sweep + calibration kernels)
+python3 tools/pmc_summarize.py $out $out/summary > $out/summary.log 2>&1 || echo "summarize failed"
+find $out -name "*counter_collection.csv" -size +4M -delete
+find $out -name "*kernel_trace.csv" -size +4M -delete
 find $out -name "*kernel_stats.csv" | head -3

@@ -60,6 +60,29 @@ bool g_setup_done = false;
 
 }  // namespace
 
+namespace {
+// process-wide defaults of the run-time options: every ensemble created afterwards (the Tier-1 entry points
+// create theirs internally) starts from them
+struct Defaults { SweepOpts sweep{}; int sync_checks = 0; int exact_sum_serial = 0; } g_defaults;
+
+// one table for both setters: key -> the int it controls and its admitted range
+int set_option_in(SweepOpts& o, int& sync_checks, int& exact_serial, const char* key, int value)
+{
+    struct Ent { const char* key; int* p; int lo, hi; };
+    const Ent tab[] = {{"tb_T", &o.T, 1, tb_max_T()}, {"kernel", &o.kernel, 0, 3}, {"q_exact_only", &o.q_exact_only, 0, 1},
+                       {"elision", &o.elision, 0, 1}, {"tile", &o.tile, 0, 9999}, {"sync_checks", &sync_checks, 0, 1},
+                       {"exact_sum_serial", &exact_serial, 0, 1}};
+    if (!key) return fail(XEE_ERR_INVALID_ARGUMENT, "null option key");
+    for (const Ent& t : tab)
+        if (strcmp(t.key, key) == 0) {
+            if (value < t.lo || value > t.hi) return fail(XEE_ERR_INVALID_ARGUMENT, std::string("option ") + key + ": value out of range");
+            *t.p = value;
+            return XEE_OK;
+        }
+    return fail(XEE_ERR_INVALID_ARGUMENT, std::string("unknown option: ") + key);
+}
+}  // namespace
+
 struct xee_ensemble {
     Grid g{};
     int device = 0;
@@ -83,11 +106,13 @@ struct xee_ensemble {
     std::vector<xee_case_record_t> rec;
     xee_timing_t timing{};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    int tb_T = 6;   // iterations per temporally blocked launch (XEE_TB_T overrides)
+    SweepOpts opts{};            // sweep options (xee_ensemble_set_option; initialised from the process defaults)
+    SweepDesc last_sweep{};      // the blocked kernel the last launch used (xee_ensemble_sweep_info)
+    bool sync_checks = false;    // option "sync_checks": the plain synchronous driver instead of the pipelined one
     void* ex_ws = nullptr;       // workspace of the parallel order-exact residual norm
     void* sx_ws = nullptr;       // ... and of the order-exact sum of signed terms (EE integrals), allocated on first use
     int* ex_slow = nullptr;      // per member: chunks the last check summed term by term
-    bool exact_serial = false;   // XEE_EXACT_SUM=serial: single-lane reference-order walk instead
+    bool exact_serial = false;   // option "exact_sum_serial": single-lane reference-order walk instead
     float* base = nullptr;       // the operator's four generating planes AP, CQ, BX, BY (xee_sweep4.hip)
     bool have_base = false;      // they describe the current coefficient planes (set by assemble)
     bool base_baro = false;      // ... of the BAROTROPIC operator (BX = BY = +0: not loaded)
@@ -101,6 +126,9 @@ struct xee_ensemble {
     float* res2 = nullptr;       // second residual plane (checks alternate res / res2)
     float* snap = nullptr;       // 2 x members planes: the iterate right after each check iteration
     MemberState* st_host2 = nullptr;   // pinned, 2 x members
+    MemberState* st_view = nullptr;    // the sweeps' view of the member states in the pipelined driver: refreshed on the
+                                       // sweep stream between launches only, so that a workgroup's early exit on `active`
+                                       // is uniform although the state machine clears the flag concurrently on `cstream`
 };
 
 namespace {
@@ -181,16 +209,17 @@ int detect_uniform_planes(xee_ensemble* e)
 
 // T iterations of the blocked sweep: from the four generating planes when assemble built them
 // (fewer bytes), else from the nine coefficient planes (any coefficients, e.g. a Tier-1 caller's)
-void launch_blocked(xee_ensemble* e, const float* psi_in, float* psi_out, float* res, float alpha, int T)
+void launch_blocked(xee_ensemble* e, const float* psi_in, float* psi_out, float* res, float alpha, int T,
+                    const MemberState* st = nullptr /* default: e->st */)
 {
-    const bool no_base4 = getenv("XEE_NO_BASE4") != nullptr;   // A/B switch for tests and probes
-    if (e->have_base && !no_base4) {
-        static const bool no_fastq = getenv("XEE_NO_FASTQ") != nullptr;   // A/B switch: the plain IEEE-division kernel
-        if (no_fastq) launch_sweep_tb4(e->g, psi_in, psi_out, e->base, e->f, res, e->st, alpha, T, e->base_baro, e->stream);
-        else launch_sweep_q(e->g, psi_in, psi_out, e->base, e->f, res, e->st, alpha, T, e->base_baro, e->stream);
+    const int k = e->opts.kernel;
+    if (!st) st = e->st;
+    if (e->have_base && k != 1) {
+        if (k == 2) launch_sweep_tb4(e->g, psi_in, psi_out, e->base, e->f, res, st, alpha, T, e->base_baro, e->opts, &e->last_sweep, e->stream);
+        else launch_sweep_q(e->g, psi_in, psi_out, e->base, e->f, res, st, alpha, T, e->base_baro, e->opts, &e->last_sweep, e->stream);
     }
     else
-        launch_sweep_tb(e->g, psi_in, psi_out, e->coe, e->f, res, e->st, alpha, T, e->uv, e->stream);
+        launch_sweep_tb(e->g, psi_in, psi_out, e->coe, e->f, res, st, alpha, T, e->uv, e->opts, &e->last_sweep, e->stream);
 }
 
 int check_launch(const char* what)
@@ -298,8 +327,9 @@ int xee_ensemble_create(xee_ensemble_t** out, int nr, int nz, int n_members, int
     e->g.pitch = ((nr + 63) / 64) * 64;
     e->g.members = n_members;
     e->g.plane = (size_t)e->g.pitch * nz;
-    if (const char* tv = getenv("XEE_TB_T")) { int t = atoi(tv); if (t >= 1 && t <= tb_max_T()) e->tb_T = t; }
-    if (const char* ev = getenv("XEE_EXACT_SUM")) e->exact_serial = (strcmp(ev, "serial") == 0);
+    e->opts = g_defaults.sweep;
+    e->sync_checks = g_defaults.sync_checks != 0;
+    e->exact_serial = g_defaults.exact_sum_serial != 0;
     int st = XEE_OK;
     auto guard = [&](int s) { if (st == XEE_OK) st = s; };
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return fail(XEE_ERR_HIP, "hipStreamCreate failed"); }
@@ -351,6 +381,7 @@ int xee_ensemble_destroy(xee_ensemble_t* e)
     if (e->res2) hipFree(e->res2);
     if (e->snap) hipFree(e->snap);
     if (e->st_host2) hipHostFree(e->st_host2);
+    if (e->st_view) hipFree(e->st_view);
     if (e->st_host) hipHostFree(e->st_host);
     if (e->sums_host) hipHostFree(e->sums_host);
     for (auto& ev : e->ev) if (ev) hipEventDestroy(ev);
@@ -378,6 +409,38 @@ int xee_ensemble_set_case_ids(xee_ensemble_t* e, int first_case_id)
     if (!e) return fail(XEE_ERR_INVALID_ARGUMENT, "null ensemble");
     e->first_case_id = first_case_id;
     for (int m = 0; m < e->g.members; ++m) e->rec[m].case_id = first_case_id + m;
+    return XEE_OK;
+}
+
+int xee_set_default_option(const char* key, int value)
+{
+    return set_option_in(g_defaults.sweep, g_defaults.sync_checks, g_defaults.exact_sum_serial, key, value);
+}
+
+int xee_reset_default_options(void)
+{
+    g_defaults = Defaults{};
+    return XEE_OK;
+}
+
+int xee_ensemble_set_option(xee_ensemble_t* e, const char* key, int value)
+{
+    if (!e) return fail(XEE_ERR_INVALID_ARGUMENT, "null ensemble");
+    int sc = e->sync_checks ? 1 : 0, xs = e->exact_serial ? 1 : 0;
+    XCHK(set_option_in(e->opts, sc, xs, key, value));
+    e->sync_checks = sc != 0;
+    e->exact_serial = xs != 0;
+    return XEE_OK;
+}
+
+int xee_ensemble_sweep_info(xee_ensemble_t* e, char* name, int name_len, int* T, int* tile_w, int* tile_h)
+{
+    if (!e) return fail(XEE_ERR_INVALID_ARGUMENT, "null ensemble");
+    if (e->opts.T == 1) e->last_sweep = SweepDesc{"k_sweep_stream", 1, e->g.nx, e->g.ny};   // one iteration per launch, no tiles
+    if (name && name_len > 0) { strncpy(name, e->last_sweep.name, (size_t)name_len - 1); name[name_len - 1] = 0; }
+    if (T) *T = e->last_sweep.T;
+    if (tile_w) *tile_w = e->last_sweep.tile_w;
+    if (tile_h) *tile_h = e->last_sweep.tile_h;
     return XEE_OK;
 }
 
@@ -514,7 +577,15 @@ int solve_pipelined(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float 
         for (auto& ev : e->evF) HIPCHK(hipEventCreate(&ev));
         for (auto& pr : e->evB) for (auto& ev : pr) HIPCHK(hipEventCreate(&ev));
         HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->st_host2), sizeof(MemberState) * 2 * g.members));
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->st_view), sizeof(MemberState) * g.members));
     }
+    // (a stale view only costs work: a member found stopped keeps iterating until the next refresh and its result is
+    // taken from the snapshot of its stopping check anyway)
+    auto refresh_view = [&]() -> int {
+        HIPCHK(hipMemcpyAsync(e->st_view, e->st, sizeof(MemberState) * g.members, hipMemcpyDeviceToDevice, s));
+        return XEE_OK;
+    };
+    XCHK(refresh_view());
     XCHK(alloc_planes(e, &e->res2));
     XCHK(alloc_planes(e, &e->snap, 2));
     hipStream_t c = e->cstream;
@@ -554,18 +625,18 @@ int solve_pipelined(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float 
         const bool check = cnt == next_check, last = cnt == max_iter;
         const int pk = k & 1;
         if (!block_open) { HIPCHK(hipEventRecord(e->evB[pk][0], s)); block_open = true; }
-        if (check && k >= 2) HIPCHK(hipStreamWaitEvent(s, e->evF[pk], 0));   // res/snap slot pk is free again
+        if (check && k >= 2) { HIPCHK(hipStreamWaitEvent(s, e->evF[pk], 0)); XCHK(refresh_view()); }   // res/snap slot pk is free again
         if (n == 1)
-            launch_sweep(g, e->psi[cur], e->psi[cur ^ 1], e->coe, e->f, check ? resbuf[pk] : nullptr, e->st, alpha, s);
+            launch_sweep(g, e->psi[cur], e->psi[cur ^ 1], e->coe, e->f, check ? resbuf[pk] : nullptr, e->st_view, alpha, s);
         else
-            launch_blocked(e, e->psi[cur], e->psi[cur ^ 1], check ? resbuf[pk] : nullptr, alpha, n);
+            launch_blocked(e, e->psi[cur], e->psi[cur ^ 1], check ? resbuf[pk] : nullptr, alpha, n, e->st_view);
         cur ^= 1;
         e->timing.sweep_launches += 1;
         e->timing.iterations += n;
         if (check) {
             HIPCHK(hipEventRecord(e->evB[pk][1], s));
             block_open = false;
-            launch_copy_active(g, e->psi[cur], snapbuf[pk], e->st, s);        // the iterate this check belongs to
+            launch_copy_active(g, e->psi[cur], snapbuf[pk], e->st_view, s);   // the iterate this check belongs to
             HIPCHK(hipEventRecord(e->evE[pk], s));
             HIPCHK(hipStreamWaitEvent(c, e->evE[pk], 0));
             if (e->exact_serial) launch_seqsum(g, resbuf[pk], 1, g.nx - 1, 1, g.ny - 1, true, e->sums, e->st, c);
@@ -612,6 +683,14 @@ int solve_pipelined(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float 
         HIPCHK(hipMemcpyAsync(e->psi[cur] + (size_t)m * g.plane, snapbuf[stop_slot[m]] + (size_t)m * g.plane,
                               sizeof(float) * g.plane, hipMemcpyDeviceToDevice, s));
     }
+    // XEE_F_RESIDUAL = the residual plane of each member's LAST check (include/xee.h): checks alternated between two
+    // planes; a stopped member's is the one of its stopping check, everyone else's the one of the last check enqueued
+    for (int m = 0; m < g.members && k >= 1; ++m) {
+        const int slot = stop_slot[m] >= 0 ? stop_slot[m] : ((k - 1) & 1);
+        if (slot == 1)
+            HIPCHK(hipMemcpyAsync(e->res + (size_t)m * g.plane, e->res2 + (size_t)m * g.plane, sizeof(float) * g.plane,
+                                  hipMemcpyDeviceToDevice, s));
+    }
     HIPCHK(hipStreamSynchronize(s));
     e->cur = cur;
     return XEE_OK;
@@ -648,11 +727,11 @@ int xee_ensemble_solve(xee_ensemble_t* e, int max_iter, int check_step, int conv
     int cur = e->cur;                                   // plane holding the newest iterate
     std::vector<int> final_buf(g.members, cur);        // plane a member's result was written to
     std::vector<char> was_active(g.members, 1);
-    const int tb_T = (flags & XEE_SOLVE_SINGLE_STEP) ? 1 : e->tb_T;
+    const int tb_T = (flags & XEE_SOLVE_SINGLE_STEP) ? 1 : e->opts.T;
 
-    // default: residual checks pipelined behind the sweeps; XEE_SYNC_CHECKS=1 (or the per-check
+    // default: residual checks pipelined behind the sweeps; option "sync_checks" (or the per-check
     // trace, whose lines must appear in order) selects the simple synchronous driver below
-    if (!getenv("XEE_SYNC_CHECKS") && cp.debug == 0) {
+    if (!e->sync_checks && cp.debug == 0) {
         XCHK(solve_pipelined(e, max_iter, cs, cp, alpha, tb_T));
         for (int m = 0; m < g.members; ++m) {
             xee_case_record_t& r = e->rec[m];
@@ -927,7 +1006,7 @@ int xee_ensemble_time_sweeps(xee_ensemble_t* e, int iters, int variant, float al
     int cur = e->cur;
     HIPCHK(hipEventRecord(e->ev[0], s));
     for (int k = 0; k < iters;) {
-        const int n = variant == 0 ? 1 : ((iters - k) < e->tb_T ? (iters - k) : e->tb_T);
+        const int n = variant == 0 ? 1 : ((iters - k) < e->opts.T ? (iters - k) : e->opts.T);
         if (n == 1) launch_sweep(g, e->psi[cur], e->psi[cur ^ 1], e->coe, e->f, nullptr, e->st, alpha, s);
         else launch_blocked(e, e->psi[cur], e->psi[cur ^ 1], nullptr, alpha, n);
         cur ^= 1;

@@ -75,6 +75,20 @@ void launch_apply(const Grid& g, const float* psi, const float* coe, float* out,
 void launch_sweep(const Grid& g, const float* psi_in, float* psi_out, const float* coe,
                   const float* f, float* res /* nullptr: not written */, const MemberState* st,
                   float alpha, hipStream_t s);
+// run-time options of the sweep (xee_set_default_option / xee_ensemble_set_option; no environment variables)
+struct SweepOpts {
+    int T = 6;             // "tb_T": iterations per temporally blocked launch, 1..tb_max_T()
+    int kernel = 0;        // "kernel": 0 auto | 1 nine coefficient planes (k_sweep_tb) | 2 generating planes, IEEE
+                           //           division (k_sweep_tb4) | 3 generating planes, hoisted reciprocal (k_sweep_q)
+    int q_exact_only = 0;  // "q_exact_only": k_sweep_q runs its exact body on every tile
+    int elision = 1;       // "elision": k_sweep_tb skips coefficient planes that are uniform over the batch
+    int tile = 0;          // "tile": NW*100 + R (waves x rows per lane), 0 = the kernel's default
+};
+// what the last blocked launch was (xee_ensemble_sweep_info)
+struct SweepDesc {
+    const char* name = "none";
+    int T = 0, tile_w = 0, tile_h = 0;
+};
 // coefficient planes that hold one bit pattern over the interior of every member (set by assemble)
 struct UniformVals {
     unsigned mask;   // bit k: plane k is uniform
@@ -84,17 +98,20 @@ void launch_uniform_check(const Grid& g, const float* coe, unsigned* differs /* 
 // T damped-Jacobi iterations in one launch (temporally blocked kernel), 2 <= T <= tb_max_T()
 void launch_sweep_tb(const Grid& g, const float* psi_in, float* psi_out, const float* coe,
                      const float* f, float* res /* residual of the LAST iteration, or nullptr */,
-                     const MemberState* st, float alpha, int T, const UniformVals& uv, hipStream_t s);
+                     const MemberState* st, float alpha, int T, const UniformVals& uv, const SweepOpts& o,
+                     SweepDesc* desc, hipStream_t s);
 // the same blocked sweep fed by the operator's four generating planes AP, CQ, BX, BY (xee_sweep4.hip):
 // base + k*members*plane, k = 0..3; the nine weights are rebuilt in the kernel prologue
 void launch_base_planes(const Grid& g, const float* sA, const float* sB /* nullptr: B = 0 */, const float* sC,
                         float* base, float dx, float dy, hipStream_t s);
 void launch_sweep_tb4(const Grid& g, const float* psi_in, float* psi_out, const float* base, const float* f,
-                      float* res, const MemberState* st, float alpha, int T, bool barotropic, hipStream_t s);
+                      float* res, const MemberState* st, float alpha, int T, bool barotropic, const SweepOpts& o,
+                      SweepDesc* desc, hipStream_t s);
 // the same, with the loop-invariant half of the update's division hoisted and a validated optimistic body
 // per tile (xee_sweepq.hip); bit-identical to launch_sweep_tb4
 void launch_sweep_q(const Grid& g, const float* psi_in, float* psi_out, const float* base, const float* f,
-                    float* res, const MemberState* st, float alpha, int T, bool barotropic, hipStream_t s);
+                    float* res, const MemberState* st, float alpha, int T, bool barotropic, const SweepOpts& o,
+                    SweepDesc* desc, hipStream_t s);
 void launch_quotient_check(unsigned long long seed, int blocks, int per_thread, int d_exp_lo, int d_exp_hi,
                            unsigned long long* mismatches /* device, 2 words */, float* first_bad /* device, 2 */,
                            hipStream_t s);

@@ -773,32 +773,23 @@ static void launch_tb_cfg(const Grid& g, const float* psi_in, float* psi_out, co
 int tb_max_T() { return 16; }
 
 void launch_sweep_tb(const Grid& g, const float* psi_in, float* psi_out, const float* coe, const float* f,
-                     float* res, const MemberState* st, float alpha, int T, const UniformVals& uv, hipStream_t s)
+                     float* res, const MemberState* st, float alpha, int T, const UniformVals& uv, const SweepOpts& o,
+                     SweepDesc* desc, hipStream_t s)
 {
-    // tile shape: NW waves x R rows (x 64 columns).  XEE_TB_CFG=<NW>x<R> overrides for experiments.
-    static const int cfg = [] {
-        const char* e = getenv("XEE_TB_CFG");
-        int nw = 0, r = 0;
-        if (e && sscanf(e, "%dx%d", &nw, &r) == 2) return nw * 100 + r;
-        return 0;
-    }();
+    // tile shape: NW waves x R rows (x 64 columns); option "tile" = NW*100+R overrides for experiments
     constexpr unsigned BARO = 0x145u;     // planes 1,3,7,9 of the reference's numbering (corner coefficients)
-    const bool baro = (uv.mask & BARO) == BARO && !getenv("XEE_NO_ELISION");
+    const bool baro = (uv.mask & BARO) == BARO && o.elision;
+    int cfg = o.tile;
+    if (cfg != 816 && cfg != 808 && cfg != 416) cfg = baro ? 808 : 416;   // measured best on MI355X (profiles/r01)
+    if (desc) { desc->name = baro ? "k_sweep_tb<elided>" : "k_sweep_tb"; desc->T = T; desc->tile_w = 64; desc->tile_h = (cfg / 100) * (cfg % 100); }
 #define TB_CASE(NW, R) case NW * 100 + R: \
         if (baro) launch_tb_cfg<NW, R, BARO>(g, psi_in, psi_out, coe, f, res, st, alpha, T, uv, s); \
         else launch_tb_cfg<NW, R, 0u>(g, psi_in, psi_out, coe, f, res, st, alpha, T, uv, s); \
         break;
     switch (cfg) {
         TB_CASE(8, 16)
-        TB_CASE(8, 12)
         TB_CASE(8, 8)
-        TB_CASE(4, 12)
-        TB_CASE(4, 8)
-        TB_CASE(2, 16)
-        TB_CASE(16, 8)
-        default:   // measured best on MI355X (profiles/r01): 2 workgroups per CU so loads overlap compute
-            if (baro) launch_tb_cfg<8, 8, BARO>(g, psi_in, psi_out, coe, f, res, st, alpha, T, uv, s);
-            else launch_tb_cfg<4, 16, 0u>(g, psi_in, psi_out, coe, f, res, st, alpha, T, uv, s);
+        TB_CASE(4, 16)
     }
 #undef TB_CASE
 }

@@ -358,268 +358,6 @@ __global__ __launch_bounds__(NW * 64, (BARO && NW * R <= 64) ? 4 : 1) void k_swe
     stamp<STAMP>(tg, 6);
 }
 
-// ---- the slim star kernel (BAROTROPIC), opt-in: XEE_SLIM_ROWS=4|6|8 -----------------------------------
-// The timeline probe shows a workgroup's step loop bound by its own latencies (a barrier and an LDS round trip
-// per step): two workgroups inside the loop at the same time each run it as fast as one alone.  With 127 VGPRs
-// only two workgroups fit a CU and one of them is usually loading or storing.  This form of the optimistic
-// BAROTROPIC body was written to fit three or four (<= 80 / 64 VGPRs, <= 40 KiB of LDS).  It is bit-exact
-// (tests/test_gpu_quotient.py) but NOT faster as compiled today: at eight rows per lane the compiler spills
-// inside the step loop (8.3 cases/s), at six rows and 80 VGPRs it runs three workgroups per CU at 12.2, at four
-// rows and 59 VGPRs four per CU at 11.3 -- against 13.1-13.4 for k_sweep_q<8,8>; per processed point the four-row
-// form is 12 % ahead, which the larger halo share of a 64x32 tile eats.  Kept for the next round (hand-scheduled
-// loop, or a 2-D wave grid that gives small tiles a better halo ratio).  What it does:
-//  * the star's weights are shared between neighbours instead of stored per point: w2 = CQ(i,j) and w8 = CQ(i,j-1)
-//    are the same plane one row apart, w6 = AP(i,j), and the w4 term AP(i-1,j)*psi(i-1,j) is the product the
-//    left-hand lane forms anyway, fetched by DPP -- same operands, same bits.  (cal_coe's "+ 0" on w2 and w6,
-//    elliptic_tools.f90:47,51 with BX = BY = 0, changes the bits only of a -0 entry: such a tile is left to the
-//    exact body.)  Per row a lane keeps psi, CQ, AP, coe5 in registers; f and y1 live in LDS (one ds_read_b64 per
-//    point and step); psi is updated in place.
-//  * points that never update keep their natural weights (sharing forbids zeroing them) with y1 = 0: their
-//    quotient is +-0, which leaves psi alone unless psi is -0 (then: exact body), and they are kept out of the
-//    dynamic bound -- whole lanes at the end, whole rows by a wave-uniform test.
-//  * the residual of the last step is stored as it is formed: if the tile fails validation the exact body
-//    overwrites the same points.
-// A failed tile is redone by sweep_tile<.., FAST = false> exactly as in k_sweep_q.
-typedef float xee_f2 __attribute__((ext_vector_type(2)));
-
-template <int NW, int R, bool WRITE_R>
-__device__ __forceinline__ void slim_tile(const Grid& g, const TileGeom& tg, xee_f2 (*fy)[R][64] /* [NW]: (f, y1) of each lane's points */,
-        float (*edge)[2][NW][64], int* vote /* [NW] */, const float* __restrict__ psi_in, float* __restrict__ psi_out,
-        const float* __restrict__ base, const float* __restrict__ f, float* __restrict__ res, float alpha, int T,
-        const MemberState* __restrict__ member /* or nullptr */)
-{
-    static_assert(R >= 3, "the in-place update keeps two old rows");
-    typedef xee_f2 f2;
-    constexpr int H = NW * R;
-    const int lane = tg.lane, w = tg.w, gx = tg.gx, gy0 = tg.gy0;
-    const size_t mo = tg.mo;
-
-    float p[R], cq[R], ap[R], w5[R];
-    float cq_b;
-    float dmin = 0x1p120f, dmax = 0x1p-120f;
-    bool ok = true;
-    {
-        const float* __restrict__ pm = psi_in + mo;
-        const float* __restrict__ fm = f + mo;
-        const float* __restrict__ apm = base + mo;
-        const float* __restrict__ cqm = base + tg.ks + mo;
-        const int cx = gx < 0 ? 0 : (gx > g.nx - 1 ? g.nx - 1 : gx);
-        auto rowoff = [&](int gy) -> size_t {
-            const int cy = gy < 0 ? 0 : (gy > g.ny - 1 ? g.ny - 1 : gy);
-            return (size_t)cy * (size_t)g.pitch;
-        };
-        float rf[R];
-        cq_b = (cqm + rowoff(gy0 - 1))[cx];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const size_t o = rowoff(gy0 + r);
-            p[r] = (pm + o)[cx];
-            rf[r] = (fm + o)[cx];
-            ap[r] = (apm + o)[cx];
-            cq[r] = (cqm + o)[cx];
-        }
-        if (member && !member->active) return;              // (workgroup-uniform; looked at only after the loads are issued)
-        const int gyb = gy0 - 1;
-        if (!(tg.col_in && gyb >= 0 && gyb < g.ny)) cq_b = 0.0f;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int gy = gy0 + r;
-            const bool in = tg.col_in && gy >= 0 && gy < g.ny;
-            const bool interior = tg.col_int && gy >= 1 && gy <= g.ny - 2;
-            if (!in) { p[r] = 0.0f; ap[r] = 0.0f; cq[r] = 0.0f; }
-            const float Am = qshr1(ap[r]);
-            const float Cm = r > 0 ? cq[r - 1] : cq_b;
-            w5[r] = -(Am + ap[r] + Cm + cq[r]);             // elliptic_tools.f90:50
-            const float d = -w5[r];
-            const float yy = interior ? quotient_y1(d) : 0.0f;
-            fy[w][r][lane] = f2{rf[r], yy};
-            dmin = interior ? __builtin_fminf(dmin, __builtin_fabsf(d)) : dmin;
-            dmax = interior ? __builtin_fmaxf(dmax, __builtin_fabsf(d)) : dmax;
-            // what the sharing / the select-free update cannot represent exactly: a -0 weight, a -0 value at a
-            // point that must not change
-            ok = ok && __builtin_bit_cast(unsigned, ap[r]) != 0x80000000u && __builtin_bit_cast(unsigned, cq[r]) != 0x80000000u &&
-                 (interior || __builtin_bit_cast(unsigned, p[r]) != 0x80000000u);
-        }
-    }
-
-    // rows of this wave that update (wave-uniform): the dynamic bound looks at those only
-    const bool all_rows_int = gy0 >= 1 && gy0 + R - 1 <= g.ny - 2;
-    float amax = 0.0f, amin = __builtin_inff();
-    auto step = [&](auto all_int_tag, int t) {
-        constexpr bool ALL_INT = decltype(all_int_tag)::value;
-        const int par = t & 1;
-        __syncthreads();
-        const float below = (w > 0) ? edge[par][0][w - 1][lane] : 0.0f;
-        const float above = (w < NW - 1) ? edge[par][1][w + 1][lane] : 0.0f;
-        auto row = [&](int r, float om, float oc, float on) -> float {
-            const f2 fyv = fy[w][r][lane];
-            const float Cm = r > 0 ? cq[r - 1] : cq_b;
-            // the star of elliptic_tools.f90:77-85 in its order (terms 2, 4, 5, 6, 8), then :190 and :238
-            float Rv = cq[r] * on;
-            Rv = Rv + qshr1(ap[r] * oc);
-            Rv = Rv + w5[r] * oc;
-            Rv = Rv + ap[r] * qshl1(oc);
-            Rv = Rv + Cm * om;
-            Rv = Rv - fyv.x;
-            const float a = alpha * Rv;
-            const bool row_int = ALL_INT || (gy0 + r >= 1 && gy0 + r <= g.ny - 2);     // scalar
-            if (row_int) {
-                amax = __builtin_fmaxf(amax, __builtin_fabsf(a));
-                amin = __builtin_fminf(amin, __builtin_fabsf(a));
-            }
-            if (WRITE_R && t == T - 1) {
-                const int gy = gy0 + r, ly = w * R + r;
-                const bool vy = (ly >= T || tg.y0 <= 0) && (ly < H - T || tg.y0 + H - 1 >= g.ny - 1);
-                if (tg.vx && vy && tg.col_int && row_int && gy >= 1 && gy <= g.ny - 2) res[mo + (size_t)gy * g.pitch + gx] = Rv;
-            }
-            return oc + quotient_q2(a, w5[r], fyv.y);
-        };
-        // in place: a row's old value is kept just as long as its upper neighbour needs it
-        float prev_old = p[0], old1 = 0.0f;
-#pragma unroll
-        for (int r = 1; r < R - 1; ++r) {
-            const float cur_old = p[r];
-            if (r == 1) old1 = cur_old;
-            p[r] = row(r, prev_old, cur_old, p[r + 1]);
-            prev_old = cur_old;
-        }
-        const float last_old = p[R - 1];
-        p[0] = row(0, below, p[0], old1);
-        p[R - 1] = row(R - 1, prev_old, last_old, above);
-        if (t + 1 < T) {
-            edge[par ^ 1][0][w][lane] = p[R - 1];
-            edge[par ^ 1][1][w][lane] = p[0];
-        }
-    };
-    edge[0][0][w][lane] = p[R - 1];
-    edge[0][1][w][lane] = p[0];
-    if (all_rows_int) {
-        for (int t = 0; t < T; ++t) step(std::true_type{}, t);
-    } else {
-        for (int t = 0; t < T; ++t) step(std::false_type{}, t);
-    }
-
-    {
-        ok = ok && dmin >= 0x1p-120f && dmax <= 0x1p120f;
-        const float a_lo = __builtin_fmaxf(0x1p-100f, dmax * 0x1p-120f);
-        const float a_hi = __builtin_fminf(0x1p100f, dmin * 0x1p94f);
-        ok = ok && (!tg.col_int || (amin >= a_lo && amax <= a_hi));
-#pragma unroll
-        for (int r = 0; r < R; ++r) ok = ok && __builtin_fabsf(p[r]) <= FLT_MAX;        // false for NaN too
-        // one-barrier vote
-        const bool wave_bad = __builtin_amdgcn_ballot_w64(!ok) != 0;
-        if (lane == 0) vote[w] = wave_bad ? 1 : 0;
-        __syncthreads();
-        const int v = vote[lane % NW];
-        if (__builtin_amdgcn_ballot_w64(v != 0) != 0) {
-            // Rare: redo the tile exactly.  The planes in registers and (f, y1) in LDS are still good; psi was
-            // updated in place and is read again.  Same layout, the reference's full arithmetic: nine terms
-            // (the corner weights are the constants cal_coe produces for BX = BY = 0), cal_coe's "+ 0" on w2 and
-            // w6, the IEEE division, a select for the points that do not update.
-            __syncthreads();                              // (everyone has read the flags before the slot is reused)
-            {
-                const float* __restrict__ pm = psi_in + mo;
-                const int cx = gx < 0 ? 0 : (gx > g.nx - 1 ? g.nx - 1 : gx);
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int gy = gy0 + r;
-                    const int cy = gy < 0 ? 0 : (gy > g.ny - 1 ? g.ny - 1 : gy);
-                    const float v0 = (pm + (size_t)cy * (size_t)g.pitch)[cx];
-                    p[r] = (tg.col_in && gy >= 0 && gy < g.ny) ? v0 : 0.0f;
-                }
-            }
-            auto xstep = [&](int t) {
-                const int par = t & 1;
-                __syncthreads();
-                const float below = (w > 0) ? edge[par][0][w - 1][lane] : 0.0f;
-                const float above = (w < NW - 1) ? edge[par][1][w + 1][lane] : 0.0f;
-                auto row = [&](int r, float om, float oc, float on) -> float {
-                    const float Cm = r > 0 ? cq[r - 1] : cq_b;
-                    const float w1 = -(0.0f + 0.0f), w3 = 0.0f + 0.0f, w7 = 0.0f + 0.0f, w9 = -(0.0f + 0.0f);   // elliptic_tools.f90:46,48,52,54
-                    const float w2 = cq[r] + (0.0f - 0.0f);                    // :47
-                    const float w4 = qshr1(ap[r]) - (0.0f - 0.0f);             // :49
-                    const float w6 = ap[r] + (0.0f - 0.0f);                    // :51
-                    const float w8 = Cm - (0.0f - 0.0f);                       // :53
-                    float Rv = w1 * qshr1(on);                                 // :77-85, left to right
-                    Rv = Rv + w2 * on;
-                    Rv = Rv + w3 * qshl1(on);
-                    Rv = Rv + w4 * qshr1(oc);
-                    Rv = Rv + w5[r] * oc;
-                    Rv = Rv + w6 * qshl1(oc);
-                    Rv = Rv + w7 * qshr1(om);
-                    Rv = Rv + w8 * om;
-                    Rv = Rv + w9 * qshl1(om);
-                    Rv = Rv - fy[w][r][lane].x;                                // :190
-                    const float upd = oc + alpha * Rv / (-w5[r]);              // :238
-                    const int gy = gy0 + r;
-                    const bool interior = tg.col_int && gy >= 1 && gy <= g.ny - 2;
-                    if (WRITE_R && t == T - 1) {
-                        const int ly = w * R + r;
-                        const bool vy = (ly >= T || tg.y0 <= 0) && (ly < H - T || tg.y0 + H - 1 >= g.ny - 1);
-                        if (tg.vx && vy && interior) res[mo + (size_t)gy * g.pitch + gx] = Rv;
-                    }
-                    return interior ? upd : oc;
-                };
-                float prev_old = p[0], old1 = 0.0f;
-#pragma unroll
-                for (int r = 1; r < R - 1; ++r) {
-                    const float cur_old = p[r];
-                    if (r == 1) old1 = cur_old;
-                    p[r] = row(r, prev_old, cur_old, p[r + 1]);
-                    prev_old = cur_old;
-                }
-                const float last_old = p[R - 1];
-                p[0] = row(0, below, p[0], old1);
-                p[R - 1] = row(R - 1, prev_old, last_old, above);
-                if (t + 1 < T) {
-                    edge[par ^ 1][0][w][lane] = p[R - 1];
-                    edge[par ^ 1][1][w][lane] = p[0];
-                }
-            };
-            edge[0][0][w][lane] = p[R - 1];
-            edge[0][1][w][lane] = p[0];
-            for (int t = 0; t < T; ++t) xstep(t);
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int ly = w * R + r;
-        const int gy = gy0 + r;
-        const bool vy = (ly >= T || tg.y0 <= 0) && (ly < H - T || tg.y0 + H - 1 >= g.ny - 1);
-        const bool interior = tg.col_int && gy >= 1 && gy <= g.ny - 2;
-        if (tg.vx && vy && interior) psi_out[mo + (size_t)gy * g.pitch + gx] = p[r];
-    }
-}
-
-#ifndef XEE_S_MINWAVES
-#define XEE_S_MINWAVES 6
-#endif
-template <int NW, int R, bool WRITE_R>
-__global__ __launch_bounds__(NW * 64, XEE_S_MINWAVES) void k_sweep_s(Grid g, const float* __restrict__ psi_in,
-        float* __restrict__ psi_out, const float* __restrict__ base, const float* __restrict__ f,
-        float* __restrict__ res, const MemberState* __restrict__ st, float alpha, int T)
-{
-    __shared__ xee_f2 fy[NW][R][64];
-    __shared__ float edge[2][2][NW][64];
-    __shared__ int vote[NW];
-    constexpr int H = NW * R;
-    const int m = blockIdx.z;
-    TileGeom tg;
-    tg.lane = threadIdx.x & 63;
-    tg.w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    tg.x0 = (int)blockIdx.x * (64 - 2 * T) - T;
-    tg.y0 = (int)blockIdx.y * (H - 2 * T) - T;
-    tg.gx = tg.x0 + tg.lane;
-    tg.gy0 = tg.y0 + tg.w * R;
-    tg.col_in = tg.gx >= 0 && tg.gx < g.nx;
-    tg.col_int = tg.gx >= 1 && tg.gx <= g.nx - 2;
-    tg.vx = (tg.lane >= T || tg.x0 <= 0) && (tg.lane < 64 - T || tg.x0 + 63 >= g.nx - 1);
-    tg.mo = (size_t)m * g.plane;
-    tg.ks = (size_t)g.members * g.plane;
-    tg.stamps = nullptr;
-    slim_tile<NW, R, WRITE_R>(g, tg, fy, edge, vote, psi_in, psi_out, base, f, res, alpha, T, st ? st + m : nullptr);
-}
-
 // validation kernel for the quotient identity: n pairs per thread drawn from a counter-based generator
 // over the admitted range; counts the pairs where quotient_q2 and the IEEE division differ
 __global__ __launch_bounds__(256) void k_quotient_check(unsigned long long seed, int per_thread, int d_exp_lo, int d_exp_hi,
@@ -681,47 +419,23 @@ static void launch_q_cfg(const Grid& g, const float* psi_in, float* psi_out, con
 }
 
 void launch_sweep_q(const Grid& g, const float* psi_in, float* psi_out, const float* base, const float* f,
-                    float* res, const MemberState* st, float alpha, int T, bool barotropic, hipStream_t s)
+                    float* res, const MemberState* st, float alpha, int T, bool barotropic, const SweepOpts& o,
+                    SweepDesc* desc, hipStream_t s)
 {
-    static const int exact_only = getenv("XEE_Q_EXACT_ONLY") ? 1 : 0;     // A/B switch: force the exact body
-    static const bool no_slim = getenv("XEE_NO_SLIM") != nullptr;         // A/B switch: k_sweep_q for the star too
-    static const int cfg = [] {
-        const char* e = getenv("XEE_TB_CFG");
-        int nw = 0, r = 0;
-        if (e && sscanf(e, "%dx%d", &nw, &r) == 2) return nw * 100 + r;
-        return 0;
-    }();
-    // opt-in (XEE_SLIM_ROWS=4|6|8): measured 11.3 / 12.2 / 8.3 cases/s against 13.1-13.4 for k_sweep_q<8,8>
-    static const int srows = getenv("XEE_SLIM_ROWS") ? atoi(getenv("XEE_SLIM_ROWS")) : 0;
-    if (barotropic && srows > 0 && !no_slim && !exact_only && cfg == 0) {
-        const int H = 8 * srows;
-        dim3 grid((g.nx - 1 + (64 - 2 * T) - 1) / (64 - 2 * T), (g.ny - 1 + (H - 2 * T) - 1) / (H - 2 * T), g.members);
-#define S_CASE(R) case R: \
-        if (res) hipLaunchKernelGGL((k_sweep_s<8, R, true>), grid, dim3(512), 0, s, g, psi_in, psi_out, base, f, res, st, alpha, T); \
-        else hipLaunchKernelGGL((k_sweep_s<8, R, false>), grid, dim3(512), 0, s, g, psi_in, psi_out, base, f, res, st, alpha, T); \
-        return;
-        switch (srows) {
-            S_CASE(4)
-            S_CASE(6)
-            S_CASE(8)
-        }
-#undef S_CASE
-    }
+    const int exact_only = o.q_exact_only ? 1 : 0;
+    // (the nine-weight body needs 156 VGPRs at eight rows per lane -- one workgroup per CU; at six it fits
+    // two: 8.9 against 7.1 cases/s on the baroclinic bench workload)
+    int cfg = o.tile;
+    if (cfg != 808 && cfg != 806 && cfg != 416) cfg = barotropic ? 808 : 806;
+    if (desc) { desc->name = barotropic ? "k_sweep_q<star>" : "k_sweep_q<nine>"; desc->T = T; desc->tile_w = 64; desc->tile_h = (cfg / 100) * (cfg % 100); }
 #define Q_CASE(NW, R) case NW * 100 + R: \
         if (barotropic) launch_q_cfg<NW, R, true>(g, psi_in, psi_out, base, f, res, st, alpha, T, exact_only, s); \
         else launch_q_cfg<NW, R, false>(g, psi_in, psi_out, base, f, res, st, alpha, T, exact_only, s); \
         break;
     switch (cfg) {
-        Q_CASE(8, 12)
-        Q_CASE(4, 16)
-        Q_CASE(16, 8)
-        Q_CASE(16, 4)
+        Q_CASE(8, 8)
         Q_CASE(8, 6)
-        default:
-            if (barotropic) launch_q_cfg<8, 8, true>(g, psi_in, psi_out, base, f, res, st, alpha, T, exact_only, s);
-            // (the nine-weight body needs 156 VGPRs at eight rows per lane -- one workgroup per CU; at six it fits
-            // two: 8.9 against 7.1 cases/s on the baroclinic bench workload)
-            else launch_q_cfg<8, 6, false>(g, psi_in, psi_out, base, f, res, st, alpha, T, exact_only, s);
+        Q_CASE(4, 16)
     }
 #undef Q_CASE
 }

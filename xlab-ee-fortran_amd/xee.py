@@ -91,6 +91,9 @@ def lib():
     L.xee_ensemble_destroy.argtypes = [vp]
     L.xee_ensemble_set_stream.argtypes = [vp, vp]
     L.xee_ensemble_set_case_ids.argtypes = [vp, C.c_int]
+    L.xee_set_default_option.argtypes = [C.c_char_p, C.c_int]
+    L.xee_ensemble_set_option.argtypes = [vp, C.c_char_p, C.c_int]
+    L.xee_ensemble_sweep_info.argtypes = [vp, C.c_char_p, C.c_int, _pi, _pi, _pi]
     L.xee_ensemble_set_profiles.argtypes = [vp, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_float, C.c_float]
     L.xee_ensemble_upload.argtypes = [vp, C.c_int, C.c_int, C.c_int, _f32p]
     L.xee_ensemble_download.argtypes = [vp, C.c_int, C.c_int, C.c_int, _f32p]
@@ -131,6 +134,15 @@ def device_count():
     n = C.c_int(0)
     _chk(lib().xee_device_count(C.byref(n)))
     return n.value
+
+
+def set_default_option(key, value):
+    """Process-wide default of a run-time option (include/xee.h); copied into ensembles created afterwards."""
+    _chk(lib().xee_set_default_option(key.encode(), int(value)))
+
+
+def reset_default_options():
+    _chk(lib().xee_reset_default_options())
 
 
 # ---- Tier 1 wrappers (same names and argument meaning as the reference procedures) ----------
@@ -357,6 +369,17 @@ class Ensemble:
     def set_case_ids(self, first):
         _chk(lib().xee_ensemble_set_case_ids(self._h, first))
 
+    def set_option(self, key, value):
+        _chk(lib().xee_ensemble_set_option(self._h, key.encode(), int(value)))
+
+    def sweep_info(self):
+        """-> dict(name, kernel, T, tile): the sweep kernel the last solve launched."""
+        buf = C.create_string_buffer(64)
+        T, tw, th = C.c_int(), C.c_int(), C.c_int()
+        _chk(lib().xee_ensemble_sweep_info(self._h, buf, 64, C.byref(T), C.byref(tw), C.byref(th)))
+        name = buf.value.decode()
+        return {"name": name, "kernel": name.split("<")[0], "T": T.value, "tile": f"{tw.value}x{th.value}"}
+
     def set_profiles(self, prof):
         self.prof = prof
         _chk(lib().xee_ensemble_set_profiles(self._h, prof["ra"], prof["za"], prof["rcuva"], prof["rho"],
@@ -433,7 +456,7 @@ class Ensemble:
 
 
 def diagnose_case(A, B, Cc, bc, forcing=None, *, mode=("DYNAMIC_EFFICIENCY", "CYLINDRICAL", "DENSITY_NORMAL", "BAROTROPIC"),
-                  domain=(0.0, 1.0, 0.0, 1.0), r1=5e-3, r2=5e-3, max_iter=100000, alpha=1.0, flags=0, Q=None):
+                  domain=(0.0, 1.0, 0.0, 1.0), r1=5e-3, r2=5e-3, max_iter=100000, alpha=1.0, flags=0, Q=None, options=None):
     """Host-side mirror of the reference driver for a batch of cases sharing one grid:
     src/diagnose/initialize-variables.f90:33-95 + diagnose.f90:2-55, on the GPU through the
     ensemble API.  A, B, Cc, bc (and forcing, Q) are (members, nz, nr) or (nz, nr)."""
@@ -444,6 +467,8 @@ def diagnose_case(A, B, Cc, bc, forcing=None, *, mode=("DYNAMIC_EFFICIENCY", "CY
     prof = profiles(nr, nz, geometry, dens, domain)
     out = {"profiles": prof}
     with Ensemble(nr, nz, members) as ens:
+        for k, v in (options or {}).items():
+            ens.set_option(k, v)
         ens.set_profiles(prof)
         ens.upload("A", A); ens.upload("B", B); ens.upload("C", Cc); ens.upload("BC_INIT", bc)
         if mode[0] == "DYNAMIC_EFFICIENCY":
@@ -462,7 +487,7 @@ def diagnose_case(A, B, Cc, bc, forcing=None, *, mode=("DYNAMIC_EFFICIENCY", "CY
                 out["solver"] = (ens.download("SOLVER_A"), ens.download("SOLVER_B"), ens.download("SOLVER_C"))
             rec = ens.solve(max_iter, r1, r2, alpha, flags=flags)  # diagnose.f90:9-15
             res = {"psi": ens.download("PSI"), "iters": rec["iters"].copy(), "err": rec["err_bits"].copy(),
-                   "r1": rec["err_now"].copy(), "r2": rec["ratio"].copy(), "timing": ens.timing()}
+                   "r1": rec["err_now"].copy(), "r2": rec["ratio"].copy(), "timing": ens.timing(), "sweep": ens.sweep_info()}
             if mode[0] == "DYNAMIC_EFFICIENCY":
                 ens.cal_eta()
                 res["eta"] = ens.download("ETA")
