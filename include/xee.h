@@ -55,7 +55,7 @@ int         xee_device_count(int *count);  /* number of visible HIP devices (0 i
  * and are copied into every ensemble at creation (the Tier-1 entry points create theirs internally);
  * xee_ensemble_set_option changes one ensemble.  Every combination gives bit-identical results -- the options
  * choose between implementations of the same arithmetic (tests run them against each other and the oracle):
- *   "tb_T"             iterations per temporally blocked sweep launch, 1..16 (6); 1 = the streaming kernel
+ *   "tb_T"             iterations per temporally blocked sweep launch, 1..16 (8); 1 = the streaming kernel
  *   "kernel"           0 auto | 1 nine coefficient planes (k_sweep_tb) | 2 generating planes with the IEEE
  *                      division (k_sweep_tb4) | 3 generating planes, hoisted reciprocal (k_sweep_q; auto's choice
  *                      whenever xee_ensemble_assemble / xee_cal_coe built the planes)
@@ -239,6 +239,9 @@ typedef struct {
     int64_t sweep_launches; /* number of sweep kernel launches in the last solve */
     int64_t iterations;     /* Jacobi iterations enqueued in the last solve (per member) */
     int64_t check_launches; /* residual-norm / state-machine launches */
+    int64_t redo_tiles;     /* tiles the LAST residual-writing sweep launch left to the exact body (k_sweep_q's optimistic
+                               body rejected them: zero residuals, non-finite iterates, exotic coefficients); 0 on the
+                               common path -- a diagnostic of how often the fallback runs */
 } xee_timing_t;
 
 /* flags of xee_ensemble_solve */

@@ -126,6 +126,7 @@ struct xee_ensemble {
     float* res2 = nullptr;       // second residual plane (checks alternate res / res2)
     float* snap = nullptr;       // 2 x members planes: the iterate right after each check iteration
     MemberState* st_host2 = nullptr;   // pinned, 2 x members
+    int* redo = nullptr;               // tile list of k_sweep_q's residual-writing launches (xee_sweepq.hip)
     MemberState* st_view = nullptr;    // the sweeps' view of the member states in the pipelined driver: refreshed on the
                                        // sweep stream between launches only, so that a workgroup's early exit on `active`
                                        // is uniform although the state machine clears the flag concurrently on `cstream`
@@ -188,6 +189,16 @@ int field_ref(xee_ensemble* e, int field, float** base, int* n1, int* n2)
 
 int check_launch(const char* what);
 
+// The sweep stream gets the device's highest priority, the residual-check stream the lowest: checks run in the
+// shadow of the next block's sweeps (solve_pipelined) and have a whole block of slack, so the dispatcher should hand
+// compute units to sweep workgroups first (measured: sweep launches 116 -> see profiles/r02 with the checks co-running).
+hipError_t create_stream(hipStream_t* s, bool high)
+{
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; }
+    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, high ? greatest : least);
+}
+
 // after the coefficient planes changed: find the ones that are uniform over the whole batch
 int detect_uniform_planes(xee_ensemble* e)
 {
@@ -216,7 +227,10 @@ void launch_blocked(xee_ensemble* e, const float* psi_in, float* psi_out, float*
     if (!st) st = e->st;
     if (e->have_base && k != 1) {
         if (k == 2) launch_sweep_tb4(e->g, psi_in, psi_out, e->base, e->f, res, st, alpha, T, e->base_baro, e->opts, &e->last_sweep, e->stream);
-        else launch_sweep_q(e->g, psi_in, psi_out, e->base, e->f, res, st, alpha, T, e->base_baro, e->opts, &e->last_sweep, e->stream);
+        else {
+            if (!e->redo && hipMalloc(reinterpret_cast<void**>(&e->redo), sizeof(int) * sweep_q_redo_ints(e->g)) != hipSuccess) { e->redo = nullptr; return; }   // (the launch check after the block reports it)
+            launch_sweep_q(e->g, psi_in, psi_out, e->base, e->f, res, st, alpha, T, e->base_baro, e->opts, e->redo, &e->last_sweep, e->stream);
+        }
     }
     else
         launch_sweep_tb(e->g, psi_in, psi_out, e->coe, e->f, res, st, alpha, T, e->uv, e->opts, &e->last_sweep, e->stream);
@@ -332,7 +346,7 @@ int xee_ensemble_create(xee_ensemble_t** out, int nr, int nz, int n_members, int
     e->exact_serial = g_defaults.exact_sum_serial != 0;
     int st = XEE_OK;
     auto guard = [&](int s) { if (st == XEE_OK) st = s; };
-    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return fail(XEE_ERR_HIP, "hipStreamCreate failed"); }
+    if (create_stream(&e->stream, true) != hipSuccess) { delete e; return fail(XEE_ERR_HIP, "hipStreamCreate failed"); }
     e->own_stream = true;
     for (auto& ev : e->ev) if (hipEventCreate(&ev) != hipSuccess) guard(fail(XEE_ERR_HIP, "hipEventCreate failed"));
     // planes every solve needs
@@ -382,6 +396,7 @@ int xee_ensemble_destroy(xee_ensemble_t* e)
     if (e->snap) hipFree(e->snap);
     if (e->st_host2) hipHostFree(e->st_host2);
     if (e->st_view) hipFree(e->st_view);
+    if (e->redo) hipFree(e->redo);
     if (e->st_host) hipHostFree(e->st_host);
     if (e->sums_host) hipHostFree(e->sums_host);
     for (auto& ev : e->ev) if (ev) hipEventDestroy(ev);
@@ -398,7 +413,7 @@ int xee_ensemble_set_stream(xee_ensemble_t* e, void* hip_stream)
     if (hip_stream) {
         e->stream = reinterpret_cast<hipStream_t>(hip_stream);
     } else {
-        HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        HIPCHK(create_stream(&e->stream, true));
         e->own_stream = true;
     }
     return XEE_OK;
@@ -438,7 +453,7 @@ int xee_ensemble_sweep_info(xee_ensemble_t* e, char* name, int name_len, int* T,
     if (!e) return fail(XEE_ERR_INVALID_ARGUMENT, "null ensemble");
     if (e->opts.T == 1) e->last_sweep = SweepDesc{"k_sweep_stream", 1, e->g.nx, e->g.ny};   // one iteration per launch, no tiles
     if (name && name_len > 0) { strncpy(name, e->last_sweep.name, (size_t)name_len - 1); name[name_len - 1] = 0; }
-    if (T) *T = e->last_sweep.T;
+    if (T) *T = e->opts.T;                      // the configured launch length (the last launch of a block may be shorter)
     if (tile_w) *tile_w = e->last_sweep.tile_w;
     if (tile_h) *tile_h = e->last_sweep.tile_h;
     return XEE_OK;
@@ -572,7 +587,7 @@ int solve_pipelined(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float 
     const Grid& g = e->g;
     hipStream_t s = e->stream;
     if (!e->cstream) {
-        HIPCHK(hipStreamCreateWithFlags(&e->cstream, hipStreamNonBlocking));
+        HIPCHK(create_stream(&e->cstream, false));
         for (auto& ev : e->evE) HIPCHK(hipEventCreate(&ev));
         for (auto& ev : e->evF) HIPCHK(hipEventCreate(&ev));
         for (auto& pr : e->evB) for (auto& ev : pr) HIPCHK(hipEventCreate(&ev));
@@ -683,6 +698,7 @@ int solve_pipelined(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float 
         HIPCHK(hipMemcpyAsync(e->psi[cur] + (size_t)m * g.plane, snapbuf[stop_slot[m]] + (size_t)m * g.plane,
                               sizeof(float) * g.plane, hipMemcpyDeviceToDevice, s));
     }
+    if (e->redo) { int n = 0; HIPCHK(hipMemcpyAsync(&n, e->redo, sizeof(int), hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s)); e->timing.redo_tiles = n; }
     // XEE_F_RESIDUAL = the residual plane of each member's LAST check (include/xee.h): checks alternated between two
     // planes; a stopped member's is the one of its stopping check, everyone else's the one of the last check enqueued
     for (int m = 0; m < g.members && k >= 1; ++m) {

@@ -77,7 +77,8 @@ void launch_sweep(const Grid& g, const float* psi_in, float* psi_out, const floa
                   float alpha, hipStream_t s);
 // run-time options of the sweep (xee_set_default_option / xee_ensemble_set_option; no environment variables)
 struct SweepOpts {
-    int T = 6;             // "tb_T": iterations per temporally blocked launch, 1..tb_max_T()
+    int T = 8;             // "tb_T": iterations per temporally blocked launch, 1..tb_max_T() (8: best on all four bench
+                           //         workloads once the prologue got cheaper, profiles/r02; round 1 used 6)
     int kernel = 0;        // "kernel": 0 auto | 1 nine coefficient planes (k_sweep_tb) | 2 generating planes, IEEE
                            //           division (k_sweep_tb4) | 3 generating planes, hoisted reciprocal (k_sweep_q)
     int q_exact_only = 0;  // "q_exact_only": k_sweep_q runs its exact body on every tile
@@ -111,7 +112,9 @@ void launch_sweep_tb4(const Grid& g, const float* psi_in, float* psi_out, const 
 // per tile (xee_sweepq.hip); bit-identical to launch_sweep_tb4
 void launch_sweep_q(const Grid& g, const float* psi_in, float* psi_out, const float* base, const float* f,
                     float* res, const MemberState* st, float alpha, int T, bool barotropic, const SweepOpts& o,
+                    int* redo /* device, sweep_q_redo_ints(g) ints: tiles a residual-writing launch leaves to the exact body */,
                     SweepDesc* desc, hipStream_t s);
+size_t sweep_q_redo_ints(const Grid& g);
 void launch_quotient_check(unsigned long long seed, int blocks, int per_thread, int d_exp_lo, int d_exp_hi,
                            unsigned long long* mismatches /* device, 2 words */, float* first_bad /* device, 2 */,
                            hipStream_t s);

@@ -1,5 +1,6 @@
 // xee_sweepq.hip -- the temporally blocked Jacobi sweep with the update's division strength-reduced,
-// optimistically, and validated per tile.
+// optimistically, and validated per tile.  (Compiled with -fno-slp-vectorize: the packed arithmetic below is
+// written out, and lane-crossing multiplies must stay scalar so that they fuse with their DPP move.)
 //
 // The reference update (xtt-lib-fortran/elliptic_tools.f90:238) divides by -coe(5): a quantity that does
 // not change between iterations.  The IEEE quotient the compiler emits for `a / d` on gfx950 is
@@ -15,7 +16,7 @@
 // the lane's interior points:
 //     static   2^-120 <= dmin, dmax <= 2^120
 //     dynamic  max(2^-100, dmax*2^-120) <= |alpha*R| <= min(2^100, dmin*2^94) at every interior point
-//              and every one of the T steps (running max/min of |alpha*R|: two instructions per point),
+//              and every one of the T steps (running max/min of |alpha*R|: one v_max3/v_min3 per two points),
 //              and every value of the tile finite at the end (non-finite values are sticky under the update)
 // which keeps the exponent difference below the 96 where div_scale starts to rescale and quotient,
 // reciprocal and remainders normal and exactly representable (tests/test_gpu_quotient.py checks the
@@ -32,6 +33,14 @@
 //  * no select for the points that never update (rim, outside the domain): their weights are set to 0, f
 //    to -1 and y1 to the zero whose sign makes q2 = -0, so `psi + q2` returns psi bit for bit and their
 //    "residual" alpha*1 stays inside the dynamic bound.
+//
+// Round 2: the optimistic body is written in PACKED fp32 (v_pk_mul/add/fma_f32: two points per instruction, each
+// half rounded separately -- the same bits as two scalar operations).  A lane's R rows are paired (k, k + R/2), so the
+// j+-1 neighbours of a pair are again a register pair (no moves except at the two ends); the i+-1 terms of the star are
+// scalar multiplies fused with their DPP lane shift (v_mul_f32_dpp: one instruction instead of shift + multiply).
+// 10 VALU instructions per point and step instead of 13.3, and for alpha == 1 (the protocol's value; 1.0f*x is x bit
+// for bit) the multiply by alpha is not issued.  Tiles that lie wholly inside the interior (most) run a prologue
+// without clamps and selects.
 #include "xee_device.h"
 
 #include <cfloat>
@@ -45,13 +54,37 @@ namespace xee {
 
 namespace {
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// old = 0 with bound_ctrl: the lane without a source reads 0, and the move folds into a following v_mul_f32 (DPP)
 __device__ __forceinline__ float qshr1(float src)   // lane l <- lane l-1 (lane 0 gets 0)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, src), 0x138, 0xf, 0xf, true));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src), 0x138, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float qshl1(float src)   // lane l <- lane l+1 (lane 63 gets 0)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, src), 0x130, 0xf, 0xf, true));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src), 0x130, 0xf, 0xf, true));
+}
+__device__ __forceinline__ f2 qshr1(f2 v) { return f2{qshr1(v.x), qshr1(v.y)}; }
+__device__ __forceinline__ f2 qshl1(f2 v) { return f2{qshl1(v.x), qshl1(v.y)}; }
+
+// Raw buffer access (buffer_load/store_dword ... offen): the row offset is a scalar operand and the column offset ONE
+// vector register shared by every access of the lane -- no per-access 64-bit address arithmetic on the VALU (the
+// compiler turns `rowbase[col]` into a v_lshl_add_u64 per load).  num_records is the byte size of one member's plane;
+// a store whose column offset is ST_DROP is dropped by the range check (no exec-mask juggling per store).
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr int ST_DROP = (int)0x80000000;
+__device__ __forceinline__ rsrc_t plane_rsrc(const float* plane_of_member, const Grid& g)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(plane_of_member), 0, (int)(g.plane * sizeof(float)), 0x00020000);
+}
+__device__ __forceinline__ float bload(rsrc_t r, int col_bytes, int row_bytes)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, col_bytes, row_bytes, 0));
+}
+__device__ __forceinline__ void bstore(rsrc_t r, int col_bytes, int row_bytes, float v)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, col_bytes, row_bytes, 0);
 }
 
 // the loop-invariant half of the quotient by d (see the header)
@@ -70,10 +103,19 @@ __device__ __forceinline__ float quotient_q2(float a, float nd, float y1)
     const float r1 = __builtin_fmaf(nd, q1, a);
     return __builtin_fmaf(r1, y1, q1);
 }
+__device__ __forceinline__ f2 quotient_q2(f2 a, f2 nd, f2 y1)   // two points per instruction
+{
+    const f2 q0 = a * y1;
+    const f2 r0 = __builtin_elementwise_fma(nd, q0, a);
+    const f2 q1 = __builtin_elementwise_fma(r0, y1, q0);
+    const f2 r1 = __builtin_elementwise_fma(nd, q1, a);
+    return __builtin_elementwise_fma(r1, y1, q1);
+}
 
 struct TileGeom {
     int lane, w, x0, y0, gx, gy0;
     bool col_in, col_int, vx;
+    bool inner;                     // the whole tile (and the row below it) lies inside the interior: workgroup-uniform
     size_t mo, ks;
     unsigned long long* stamps;     // developer timeline (tools/probe_q.hip) or nullptr
 };
@@ -89,70 +131,70 @@ __device__ __forceinline__ void stamp(const TileGeom& tg, int slot)
     }
 }
 
-// One tile, T steps.  FAST: the optimistic body; returns whether the WHOLE workgroup validated, and only
-// then stores.  !FAST: the exact body (the arithmetic of k_sweep_tb4); always stores.
-template <int NW, int R, bool WRITE_R, bool BARO, bool FAST, bool STAMP = false>
-__device__ __forceinline__ bool sweep_tile(const Grid& g, const TileGeom& tg, float (*edge)[2][NW][64], int* vote,
+// ---- the optimistic body: packed arithmetic, hoisted reciprocal, validated -------------------------------------
+// One tile, T steps.  Returns whether the WHOLE workgroup validated, and only then stores.
+// A lane holds rows gy0 .. gy0+R-1 of its column as R/2 pairs: pair k = (row k, row k + R/2).
+template <int NW, int R, bool WRITE_R, bool BARO, bool ALPHA1, bool INNER, bool STAMP>
+__device__ __forceinline__ bool fast_tile(const Grid& g, const TileGeom& tg, float (*edge)[2][NW][64], int* vote,
         const float* __restrict__ psi_in, float* __restrict__ psi_out, const float* __restrict__ base,
-        const float* __restrict__ f, float* __restrict__ res, float alpha, int T,
-        const MemberState* __restrict__ member = nullptr /* if given: return at once when it has stopped */)
+        const float* __restrict__ f, float* __restrict__ res, float alpha, int T, const MemberState* __restrict__ member)
 {
+    static_assert(R % 2 == 0 && R >= 4, "rows are processed in pairs (k, k + R/2)");
     constexpr int H = NW * R;
-    constexpr bool STAR = FAST && BARO;
-    constexpr int NC = STAR ? 5 : 9;                    // weights kept: the star (2,4,5,6,8) or all nine
-    constexpr int K5 = STAR ? 2 : 4;                    // where coe5 sits in c[]
+    constexpr int H2 = R / 2;
+    constexpr int NC = BARO ? 5 : 9;                    // weights kept: the star (2,4,5,6,8) or all nine
+    constexpr int K5 = BARO ? 2 : 4;                    // where coe5 sits in c[]
     const int lane = tg.lane, w = tg.w, gx = tg.gx, gy0 = tg.gy0;
     const size_t mo = tg.mo, ks = tg.ks;
 
-    float c[NC][R], ff[R], p[R], y1[FAST ? R : 1];
+    f2 c[NC][H2], ff[H2], y1[H2], p[H2];
     float dmin = 0x1p120f, dmax = 0x1p-120f;            // extremes of |coe5| over this lane's interior points
     {
         // Every load of the tile is issued before the first value is used, unconditionally and from a
-        // clamped (always valid) address; what lies outside the domain is replaced afterwards.  (Loading
-        // under the `in` predicate makes the compiler branch around each load and wait row by row: eight
-        // memory latencies in sequence instead of one.)
-        const float* __restrict__ pm = psi_in + mo;
-        const float* __restrict__ fm = f + mo;
-        const float* __restrict__ apm = base + mo;
-        const float* __restrict__ cqm = base + ks + mo;
-        const float* __restrict__ bxm = base + 2 * ks + mo;
-        const float* __restrict__ bym = base + 3 * ks + mo;
-        // (the wave index is scalar -- readfirstlane in the kernel -- so a row's offset is scalar arithmetic and
-        // the only per-lane part of an address is the clamped column, shared by all 4R+1 loads)
-        const int cx = gx < 0 ? 0 : (gx > g.nx - 1 ? g.nx - 1 : gx);
-        auto rowoff = [&](int gy) -> size_t {
-            const int cy = gy < 0 ? 0 : (gy > g.ny - 1 ? g.ny - 1 : gy);
-            return (size_t)cy * (size_t)g.pitch;
+        // clamped (always valid) address; what lies outside the domain is replaced afterwards.  Row offsets are
+        // scalar (the wave index is), the only per-lane part of an address is the column.
+        const rsrc_t pr = plane_rsrc(psi_in + mo, g), fr = plane_rsrc(f + mo, g);
+        const rsrc_t apr = plane_rsrc(base + mo, g), cqr = plane_rsrc(base + ks + mo, g);
+        const int cx = (INNER ? gx : (gx < 0 ? 0 : (gx > g.nx - 1 ? g.nx - 1 : gx))) * 4;
+        auto rowoff = [&](int gy) -> int {
+            const int cy = INNER ? gy : (gy < 0 ? 0 : (gy > g.ny - 1 ? g.ny - 1 : gy));
+            return cy * g.pitch * 4;
         };
         float rp[R], rf[R], rap[R], rcq[R], rbx[BARO ? 1 : R], rby[BARO ? 1 : R];
-        const size_t ob = rowoff(gy0 - 1);
-        const float rcq_b = (cqm + ob)[cx];
-        const float rby_b = BARO ? 0.0f : (bym + ob)[cx];
+        const int ob = rowoff(gy0 - 1);
+        const float rcq_b = bload(cqr, cx, ob);
+        float rby_b = 0.0f;
+        if constexpr (!BARO) rby_b = bload(plane_rsrc(base + 3 * ks + mo, g), cx, ob);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const size_t o = rowoff(gy0 + r);
-            rp[r] = (pm + o)[cx];
-            rf[r] = (fm + o)[cx];
-            rap[r] = (apm + o)[cx];
-            rcq[r] = (cqm + o)[cx];
-            if constexpr (!BARO) { rbx[r] = (bxm + o)[cx]; rby[r] = (bym + o)[cx]; }
+            const int o = rowoff(gy0 + r);
+            rp[r] = bload(pr, cx, o);
+            rf[r] = bload(fr, cx, o);
+            rap[r] = bload(apr, cx, o);
+            rcq[r] = bload(cqr, cx, o);
+            if constexpr (!BARO) {
+                rbx[r] = bload(plane_rsrc(base + 2 * ks + mo, g), cx, o);
+                rby[r] = bload(plane_rsrc(base + 3 * ks + mo, g), cx, o);
+            }
         }
         stamp<STAMP>(tg, 1);                                // loads issued
         // (only now the member's `active` flag is looked at: testing it first would put a scalar-memory round
-        // trip in front of the tile's loads; for a stopped member the loads above are harmless)
-        if (member && !member->active) return true;         // workgroup-uniform
+        // trip in front of the tile's loads; for a stopped member the loads above are harmless.  The flag a sweep
+        // sees only changes between launches -- xee_api.hip keeps a per-stream view -- so the exit is uniform)
+        if (member && !member->active) return true;
         const float y_idle = alpha > 0.0f ? -0.0f : 0.0f;   // (alpha*1) * y_idle = -0
         const int gyb = gy0 - 1;
-        const bool inb = tg.col_in && gyb >= 0 && gyb < g.ny;
+        const bool inb = INNER || (tg.col_in && gyb >= 0 && gyb < g.ny);
         float cq_m = inb ? rcq_b : 0.0f;
         float by_m = (!BARO && inb) ? rby_b : 0.0f;
+        float cw[NC][R], fw[R], yw[R], pw[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int gy = gy0 + r;
-            const bool in = tg.col_in && gy >= 0 && gy < g.ny;
-            const bool interior = tg.col_int && gy >= 1 && gy <= g.ny - 2;
-            p[r] = in ? rp[r] : 0.0f;
-            ff[r] = interior ? rf[r] : (FAST ? -1.0f : 0.0f);
+            const bool in = INNER || (tg.col_in && gy >= 0 && gy < g.ny);
+            const bool interior = INNER || (tg.col_int && gy >= 1 && gy <= g.ny - 2);
+            pw[r] = in ? rp[r] : 0.0f;
+            fw[r] = interior ? rf[r] : -1.0f;
             const float Ap = in ? rap[r] : 0.0f;
             const float Cp = in ? rcq[r] : 0.0f;
             const float BXp = (!BARO && in) ? rbx[BARO ? 0 : r] : 0.0f;
@@ -170,107 +212,266 @@ __device__ __forceinline__ bool sweep_tile(const Grid& g, const TileGeom& tg, fl
             const float w7 = BXm + BYm;
             const float w8 = Cm - (BXp - BXm);
             const float w9 = -(BXp + BYm);
-            if constexpr (FAST) {
-                if constexpr (STAR) {
-                    c[0][r] = interior ? w2 : 0.0f; c[1][r] = interior ? w4 : 0.0f; c[2][r] = interior ? w5 : 0.0f;
-                    c[3][r] = interior ? w6 : 0.0f; c[4][r] = interior ? w8 : 0.0f;
-                } else {
-                    c[0][r] = interior ? w1 : 0.0f; c[1][r] = interior ? w2 : 0.0f; c[2][r] = interior ? w3 : 0.0f;
-                    c[3][r] = interior ? w4 : 0.0f; c[4][r] = interior ? w5 : 0.0f; c[5][r] = interior ? w6 : 0.0f;
-                    c[6][r] = interior ? w7 : 0.0f; c[7][r] = interior ? w8 : 0.0f; c[8][r] = interior ? w9 : 0.0f;
-                }
-                const float d = -w5;
-                y1[r] = interior ? quotient_y1(d) : y_idle;
-                // (a NaN d passes through fmin/fmax unnoticed, but then y1 and every iterate of the point are NaN)
-                dmin = interior ? __builtin_fminf(dmin, __builtin_fabsf(d)) : dmin;
-                dmax = interior ? __builtin_fmaxf(dmax, __builtin_fabsf(d)) : dmax;
+            if constexpr (BARO) {
+                cw[0][r] = interior ? w2 : 0.0f; cw[1][r] = interior ? w4 : 0.0f; cw[2][r] = interior ? w5 : 0.0f;
+                cw[3][r] = interior ? w6 : 0.0f; cw[4][r] = interior ? w8 : 0.0f;
             } else {
-                c[0][r] = w1; c[1][r] = w2; c[2][r] = w3; c[3][r] = w4; c[4][r] = w5;
-                c[5][r] = w6; c[6][r] = w7; c[7][r] = w8; c[8][r] = w9;
+                cw[0][r] = interior ? w1 : 0.0f; cw[1][r] = interior ? w2 : 0.0f; cw[2][r] = interior ? w3 : 0.0f;
+                cw[3][r] = interior ? w4 : 0.0f; cw[4][r] = interior ? w5 : 0.0f; cw[5][r] = interior ? w6 : 0.0f;
+                cw[6][r] = interior ? w7 : 0.0f; cw[7][r] = interior ? w8 : 0.0f; cw[8][r] = interior ? w9 : 0.0f;
             }
+            const float d = -w5;
+            yw[r] = interior ? quotient_y1(d) : y_idle;
+            // (a NaN d passes through fmin/fmax unnoticed, but then y1 and every iterate of the point are NaN)
+            dmin = interior ? __builtin_fminf(dmin, __builtin_fabsf(d)) : dmin;
+            dmax = interior ? __builtin_fmaxf(dmax, __builtin_fabsf(d)) : dmax;
             cq_m = Cp;
             by_m = BYp;
+        }
+        // rows (k, k + R/2) into register pairs
+#pragma unroll
+        for (int k = 0; k < H2; ++k) {
+            p[k] = f2{pw[k], pw[k + H2]};
+            ff[k] = f2{fw[k], fw[k + H2]};
+            y1[k] = f2{yw[k], yw[k + H2]};
+#pragma unroll
+            for (int n = 0; n < NC; ++n) c[n][k] = f2{cw[n][k], cw[n][k + H2]};
         }
     }
 
     stamp<STAMP>(tg, 2);                                  // weights built
-    float amax = 0.0f, amin = __builtin_inff();           // running extremes of |alpha * R| (FAST)
-    float q[R], rl[(FAST && WRITE_R) ? R : 1];
+    float amax = 0.0f, amin = __builtin_inff();           // running extremes of |alpha * R|
+    f2 q[H2], rl[WRITE_R ? H2 : 1];
+    const f2 alpha2 = f2{alpha, alpha};
     // One Jacobi step src -> dst.  The edge rows of src are already in LDS (written by the tail of the previous
-    // step, or before the loop); after the barrier the neighbours' rows are requested and, in the star body, the
-    // rows that do not need them (1..R-2) are computed first, so the LDS round trip hides behind the step's work.
-    // (Measured alternatives, tools/probe_q.hip: the barrier costs about as much as a step's arithmetic -- 9.6k
-    // ticks per 6 steps with it, 5.7k without -- but per-neighbour flags in LDS instead are worse still, 13.9k:
-    // waves that spin on a flag take issue slots from the wave they wait for.)
+    // step, or before the loop); after the barrier the neighbours' rows are requested and the pairs that do not
+    // need them (1..H2-2) are computed first, so the LDS round trip hides behind the step's work.
+    // (Measured alternatives, tools/probe_q.hip: the barrier costs about as much as a step's arithmetic, but
+    // per-neighbour flags in LDS instead are worse still: waves that spin on a flag take issue slots from the
+    // wave they wait for.)
+    auto step = [&](const f2 (&src)[H2], f2 (&dst)[H2], int t, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;      // the launch's final step (keeps the residual)
+        const int par = t & 1;
+        __syncthreads();
+        const float below = (w > 0) ? edge[par][0][w - 1][lane] : 0.0f;
+        const float above = (w < NW - 1) ? edge[par][1][w + 1][lane] : 0.0f;
+        auto finish = [&](int k, f2 Rv) {
+            Rv = Rv - ff[k];                                           // :190
+            const f2 a = ALPHA1 ? Rv : alpha2 * Rv;
+            dst[k] = src[k] + quotient_q2(a, c[K5][k], y1[k]);         // :238, -d = coe5
+            amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(a.x)), __builtin_fabsf(a.y));
+            amin = __builtin_fminf(__builtin_fminf(amin, __builtin_fabsf(a.x)), __builtin_fabsf(a.y));
+            if constexpr (WRITE_R && LAST) rl[k] = Rv;
+        };
+        if constexpr (BARO) {
+            auto pair = [&](int k) {
+                const f2 oc = src[k];
+                const f2 on = (k + 1 < H2) ? src[k + 1] : f2{src[0].y, above};       // rows k+1, k+R/2+1
+                const f2 om = (k > 0) ? src[k - 1] : f2{below, src[H2 - 1].x};       // rows k-1, k+R/2-1
+                // the star of elliptic_tools.f90:77-85, in its order (terms 2, 4, 5, 6, 8)
+                f2 Rv = c[0][k] * on;
+                Rv = Rv + f2{c[1][k].x * qshr1(oc.x), c[1][k].y * qshr1(oc.y)};      // v_mul_f32_dpp
+                Rv = Rv + c[2][k] * oc;
+                Rv = Rv + f2{c[3][k].x * qshl1(oc.x), c[3][k].y * qshl1(oc.y)};
+                Rv = Rv + c[4][k] * om;
+                finish(k, Rv);
+            };
+#pragma unroll
+            for (int k = 1; k < H2 - 1; ++k) pair(k);
+            pair(0);
+            pair(H2 - 1);
+        } else {
+            // the i-1 / i+1 views of the old iterate: one DPP move per value, each used by three rows
+            f2 lft[H2], rgt[H2];
+#pragma unroll
+            for (int k = 0; k < H2; ++k) { lft[k] = qshr1(src[k]); rgt[k] = qshl1(src[k]); }
+            const float lb = qshr1(below), rb = qshl1(below), la = qshr1(above), ra = qshl1(above);
+#pragma unroll
+            for (int k = 0; k < H2; ++k) {
+                const f2 oc = src[k];
+                const f2 on = (k + 1 < H2) ? src[k + 1] : f2{src[0].y, above};
+                const f2 om = (k > 0) ? src[k - 1] : f2{below, src[H2 - 1].x};
+                const f2 ln = (k + 1 < H2) ? lft[k + 1] : f2{lft[0].y, la};
+                const f2 rn = (k + 1 < H2) ? rgt[k + 1] : f2{rgt[0].y, ra};
+                const f2 lm = (k > 0) ? lft[k - 1] : f2{lb, lft[H2 - 1].x};
+                const f2 rm = (k > 0) ? rgt[k - 1] : f2{rb, rgt[H2 - 1].x};
+                f2 Rv = c[0][k] * ln;                         // elliptic_tools.f90:77-85, left to right
+                Rv = Rv + c[1][k] * on;
+                Rv = Rv + c[2][k] * rn;
+                Rv = Rv + c[3][k] * lft[k];
+                Rv = Rv + c[4][k] * oc;
+                Rv = Rv + c[5][k] * rgt[k];
+                Rv = Rv + c[6][k] * lm;
+                Rv = Rv + c[7][k] * om;
+                Rv = Rv + c[8][k] * rm;
+                finish(k, Rv);
+            }
+        }
+        // the next step's exchange (written after the last step too: nobody reads it, and a step body without a
+        // branch is one basic block -- the DPP moves only fold into their multiplies inside a block)
+        edge[par ^ 1][0][w][lane] = dst[H2 - 1].y;            // row R-1, for the wave above
+        edge[par ^ 1][1][w][lane] = dst[0].x;                 // row 0, for the wave below
+    };
+    edge[0][0][w][lane] = p[H2 - 1].y;
+    edge[0][1][w][lane] = p[0].x;
+    int t = 0;
+    bool in_q;
+    if constexpr (WRITE_R) {
+        // the final step is its own instance (it keeps the residual): T - 1 or T - 2 steps in pairs first
+        for (; t + 2 < T; t += 2) {
+            step(p, q, t, std::false_type{});
+            step(q, p, t + 1, std::false_type{});
+        }
+        in_q = t + 1 >= T;
+        if (in_q) step(p, q, t, std::true_type{});
+        else { step(p, q, t, std::false_type{}); step(q, p, t + 1, std::true_type{}); }
+    } else {
+        for (; t + 1 < T; t += 2) {
+            step(p, q, t, std::false_type{});
+            step(q, p, t + 1, std::false_type{});
+        }
+        in_q = t < T;                                     // odd T: one more step, which writes q
+        if (in_q) step(p, q, t, std::false_type{});
+    }
+    stamp<STAMP>(tg, 3);                                  // T steps done
+
+    {
+        bool ok = dmin >= 0x1p-120f && dmax <= 0x1p120f;
+        const float a_lo = __builtin_fmaxf(0x1p-100f, dmax * 0x1p-120f);
+        const float a_hi = __builtin_fminf(0x1p100f, dmin * 0x1p94f);
+        ok = ok && amin >= a_lo && amax <= a_hi;
+#pragma unroll
+        for (int k = 0; k < H2; ++k) {
+            const f2 v = in_q ? q[k] : p[k];
+            ok = ok && __builtin_fabsf(v.x) <= FLT_MAX && __builtin_fabsf(v.y) <= FLT_MAX;   // false for NaN too
+        }
+        // one-barrier vote (__syncthreads_and takes three): a flag per wave, then every wave looks at all of them
+        const bool wave_bad = __builtin_amdgcn_ballot_w64(!ok) != 0;
+        if (lane == 0) vote[w] = wave_bad ? 1 : 0;
+        __syncthreads();
+        const int v = vote[lane % NW];
+        if (__builtin_amdgcn_ballot_w64(v != 0) != 0) return false;
+    }
+    stamp<STAMP>(tg, 4);                                  // validated
+    {
+        // a row is stored or not as a whole (scalar test); lanes outside the valid columns get a dropped offset
+        const rsrc_t outr = plane_rsrc(psi_out + mo, g);
+        const int sx = (tg.vx && (INNER || tg.col_int)) ? gx * 4 : ST_DROP;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int k = r < H2 ? r : r - H2;
+            const int ly = w * R + r;
+            const int gy = gy0 + r;
+            const bool vy = (ly >= T || tg.y0 <= 0) && (ly < H - T || tg.y0 + H - 1 >= g.ny - 1);
+            const bool row_int = INNER || (gy >= 1 && gy <= g.ny - 2);
+            if (vy && row_int) {
+                const int o = gy * g.pitch * 4;
+                const f2 v = in_q ? q[k] : p[k];
+                bstore(outr, sx, o, r < H2 ? v.x : v.y);
+                if constexpr (WRITE_R) bstore(plane_rsrc(res + mo, g), sx, o, r < H2 ? rl[k].x : rl[k].y);
+            }
+        }
+    }
+    stamp<STAMP>(tg, 5);                                  // stores issued
+    return true;
+}
+
+// ---- the exact body: the arithmetic of k_sweep_tb4 (all nine terms, IEEE division, a select for the points that
+// do not update).  Runs only for tiles the optimistic body rejected (or under the option "q_exact_only").
+template <int NW, int R, bool WRITE_R, bool BARO>
+__device__ __forceinline__ void exact_tile(const Grid& g, const TileGeom& tg, float (*edge)[2][NW][64],
+        const float* __restrict__ psi_in, float* __restrict__ psi_out, const float* __restrict__ base,
+        const float* __restrict__ f, float* __restrict__ res, float alpha, int T, const MemberState* __restrict__ member)
+{
+    constexpr int H = NW * R;
+    const int lane = tg.lane, w = tg.w, gx = tg.gx, gy0 = tg.gy0;
+    const size_t mo = tg.mo, ks = tg.ks;
+
+    float c[9][R], ff[R], p[R];
+    {
+        const float* __restrict__ pm = psi_in + mo;
+        const float* __restrict__ fm = f + mo;
+        const float* __restrict__ apm = base + mo;
+        const float* __restrict__ cqm = base + ks + mo;
+        const float* __restrict__ bxm = base + 2 * ks + mo;
+        const float* __restrict__ bym = base + 3 * ks + mo;
+        const unsigned cx = (unsigned)(gx < 0 ? 0 : (gx > g.nx - 1 ? g.nx - 1 : gx));
+        auto rowoff = [&](int gy) -> size_t {
+            const int cy = gy < 0 ? 0 : (gy > g.ny - 1 ? g.ny - 1 : gy);
+            return (size_t)cy * (size_t)g.pitch;
+        };
+        if (member && !member->active) return;
+        const int gyb = gy0 - 1;
+        const bool inb = tg.col_in && gyb >= 0 && gyb < g.ny;
+        const size_t ob = rowoff(gyb);
+        float cq_m = inb ? (cqm + ob)[cx] : 0.0f;
+        float by_m = (!BARO && inb) ? (bym + ob)[cx] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int gy = gy0 + r;
+            const size_t o = rowoff(gy);
+            const bool in = tg.col_in && gy >= 0 && gy < g.ny;
+            const bool interior = tg.col_int && gy >= 1 && gy <= g.ny - 2;
+            p[r] = in ? (pm + o)[cx] : 0.0f;
+            ff[r] = interior ? (fm + o)[cx] : 0.0f;
+            const float Ap = in ? (apm + o)[cx] : 0.0f;
+            const float Cp = in ? (cqm + o)[cx] : 0.0f;
+            const float BXp = (!BARO && in) ? (bxm + o)[cx] : 0.0f;
+            const float BYp = (!BARO && in) ? (bym + o)[cx] : 0.0f;
+            const float Am = qshr1(Ap);
+            const float BXm = BARO ? 0.0f : qshr1(BXp);
+            const float Cm = cq_m, BYm = by_m;
+            // elliptic_tools.f90:46-54
+            c[0][r] = -(BXm + BYp);
+            c[1][r] = Cp + (BXp - BXm);
+            c[2][r] = BXp + BYp;
+            c[3][r] = Am - (BYp - BYm);
+            c[4][r] = -(Am + Ap + Cm + Cp);
+            c[5][r] = Ap + (BYp - BYm);
+            c[6][r] = BXm + BYm;
+            c[7][r] = Cm - (BXp - BXm);
+            c[8][r] = -(BXp + BYm);
+            cq_m = Cp;
+            by_m = BYp;
+        }
+    }
+    float q[R];
     auto step = [&](const float (&src)[R], float (&dst)[R], int t) {
         const int par = t & 1;
         __syncthreads();
         const float below = (w > 0) ? edge[par][0][w - 1][lane] : 0.0f;
         const float above = (w < NW - 1) ? edge[par][1][w + 1][lane] : 0.0f;
-        if constexpr (STAR) {
-            auto row = [&](int r) {
-                const float om = (r > 0) ? src[r - 1] : below;
-                const float oc = src[r];
-                const float on = (r + 1 < R) ? src[r + 1] : above;
-                // the star of elliptic_tools.f90:77-85, in its order (terms 2, 4, 5, 6, 8), then :190
-                float Rv = c[0][r] * on;
-                Rv = Rv + c[1][r] * qshr1(oc);
-                Rv = Rv + c[2][r] * oc;
-                Rv = Rv + c[3][r] * qshl1(oc);
-                Rv = Rv + c[4][r] * om;
-                Rv = Rv - ff[r];
-                const float a = alpha * Rv;
-                dst[r] = oc + quotient_q2(a, c[2][r], y1[r]);              // :238, -d = coe5
-                amax = __builtin_fmaxf(amax, __builtin_fabsf(a));
-                amin = __builtin_fminf(amin, __builtin_fabsf(a));
-                if (WRITE_R && t == T - 1) rl[WRITE_R ? r : 0] = Rv;
-            };
+        float lft[R + 2], rgt[R + 2];
+        lft[0] = qshr1(below); rgt[0] = qshl1(below);
 #pragma unroll
-            for (int r = 1; r < R - 1; ++r) row(r);
-            row(0);
-            row(R - 1);
-        } else {
-            // the i-1 / i+1 views of rows -1..R of the old iterate, one DPP move each
-            float lft[R + 2], rgt[R + 2];
-            lft[0] = qshr1(below); rgt[0] = qshl1(below);
+        for (int r = 0; r < R; ++r) { lft[r + 1] = qshr1(src[r]); rgt[r + 1] = qshl1(src[r]); }
+        lft[R + 1] = qshr1(above); rgt[R + 1] = qshl1(above);
 #pragma unroll
-            for (int r = 0; r < R; ++r) { lft[r + 1] = qshr1(src[r]); rgt[r + 1] = qshl1(src[r]); }
-            lft[R + 1] = qshr1(above); rgt[R + 1] = qshl1(above);
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const float om = (r > 0) ? src[r - 1] : below;
-                const float oc = src[r];
-                const float on = (r + 1 < R) ? src[r + 1] : above;
-                float Rv = c[0][r] * lft[r + 2];              // elliptic_tools.f90:77-85, left to right
-                Rv = Rv + c[1][r] * on;
-                Rv = Rv + c[2][r] * rgt[r + 2];
-                Rv = Rv + c[3][r] * lft[r + 1];
-                Rv = Rv + c[4][r] * oc;
-                Rv = Rv + c[5][r] * rgt[r + 1];
-                Rv = Rv + c[6][r] * lft[r];
-                Rv = Rv + c[7][r] * om;
-                Rv = Rv + c[8][r] * rgt[r];
-                Rv = Rv - ff[r];                              // :190
-                if constexpr (FAST) {
-                    const float a = alpha * Rv;
-                    dst[r] = oc + quotient_q2(a, c[K5][r], y1[r]);
-                    amax = __builtin_fmaxf(amax, __builtin_fabsf(a));
-                    amin = __builtin_fminf(amin, __builtin_fabsf(a));
-                    if (WRITE_R && t == T - 1) rl[WRITE_R ? r : 0] = Rv;
-                } else {
-                    const float upd = oc + alpha * Rv / (-c[K5][r]);   // :238
-                    const int gy = gy0 + r;
-                    const bool interior = tg.col_int && gy >= 1 && gy <= g.ny - 2;
-                    dst[r] = interior ? upd : oc;
-                    if (WRITE_R && t == T - 1) {
-                        const int ly = w * R + r;
-                        const bool vy = (ly >= T || tg.y0 <= 0) && (ly < H - T || tg.y0 + H - 1 >= g.ny - 1);
-                        if (tg.vx && vy && interior) res[mo + (size_t)gy * g.pitch + gx] = Rv;
-                    }
-                }
+        for (int r = 0; r < R; ++r) {
+            const float om = (r > 0) ? src[r - 1] : below;
+            const float oc = src[r];
+            const float on = (r + 1 < R) ? src[r + 1] : above;
+            float Rv = c[0][r] * lft[r + 2];              // elliptic_tools.f90:77-85, left to right
+            Rv = Rv + c[1][r] * on;
+            Rv = Rv + c[2][r] * rgt[r + 2];
+            Rv = Rv + c[3][r] * lft[r + 1];
+            Rv = Rv + c[4][r] * oc;
+            Rv = Rv + c[5][r] * rgt[r + 1];
+            Rv = Rv + c[6][r] * lft[r];
+            Rv = Rv + c[7][r] * om;
+            Rv = Rv + c[8][r] * rgt[r];
+            Rv = Rv - ff[r];                              // :190
+            const float upd = oc + alpha * Rv / (-c[4][r]);   // :238
+            const int gy = gy0 + r;
+            const bool interior = tg.col_int && gy >= 1 && gy <= g.ny - 2;
+            dst[r] = interior ? upd : oc;
+            if (WRITE_R && t == T - 1) {
+                const int ly = w * R + r;
+                const bool vy = (ly >= T || tg.y0 <= 0) && (ly < H - T || tg.y0 + H - 1 >= g.ny - 1);
+                if (tg.vx && vy && interior) res[mo + (size_t)gy * g.pitch + gx] = Rv;
             }
         }
-        if (t + 1 < T) {                                      // the next step's exchange
+        if (t + 1 < T) {
             edge[par ^ 1][0][w][lane] = dst[R - 1];
             edge[par ^ 1][1][w][lane] = dst[0];
         }
@@ -281,68 +482,57 @@ __device__ __forceinline__ bool sweep_tile(const Grid& g, const TileGeom& tg, fl
         step(p, q, t);
         if (t + 1 < T) step(q, p, t + 1);
     }
-    const bool in_q = (T & 1) != 0;                       // odd T: the last step wrote q
-    stamp<STAMP>(tg, 3);                                  // T steps done
-
-    if constexpr (FAST) {
-        bool ok = dmin >= 0x1p-120f && dmax <= 0x1p120f;
-        const float a_lo = __builtin_fmaxf(0x1p-100f, dmax * 0x1p-120f);
-        const float a_hi = __builtin_fminf(0x1p100f, dmin * 0x1p94f);
-        ok = ok && amin >= a_lo && amax <= a_hi;
-#pragma unroll
-        for (int r = 0; r < R; ++r) ok = ok && __builtin_fabsf(in_q ? q[r] : p[r]) <= FLT_MAX;   // false for NaN too
-        // one-barrier vote (__syncthreads_and takes three): a flag per wave, then every wave looks at all of them
-        const bool wave_bad = __builtin_amdgcn_ballot_w64(!ok) != 0;
-        if (lane == 0) vote[w] = wave_bad ? 1 : 0;
-        __syncthreads();
-        const int v = vote[lane % NW];
-        if (__builtin_amdgcn_ballot_w64(v != 0) != 0) return false;
-    }
-    stamp<STAMP>(tg, 4);                                  // validated
+    const bool in_q = (T & 1) != 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int ly = w * R + r;
         const int gy = gy0 + r;
         const bool vy = (ly >= T || tg.y0 <= 0) && (ly < H - T || tg.y0 + H - 1 >= g.ny - 1);
         const bool interior = tg.col_int && gy >= 1 && gy <= g.ny - 2;
-        if (tg.vx && vy && interior) {
-            const size_t o = mo + (size_t)gy * g.pitch + gx;
-            psi_out[o] = in_q ? q[r] : p[r];
-            if constexpr (FAST && WRITE_R) res[o] = rl[r];
-        }
+        if (tg.vx && vy && interior) psi_out[mo + (size_t)gy * g.pitch + gx] = in_q ? q[r] : p[r];
     }
-    stamp<STAMP>(tg, 5);                                  // stores issued
-    return true;
 }
 
 }  // namespace
 
-// (HIP's second launch bound is waves per SIMD: 4 keeps the 8x8 BAROTROPIC kernels at 128 VGPRs, i.e. two
-// workgroups per CU, also for the residual-writing variant)
-template <int NW, int R, bool WRITE_R, bool BARO, bool STAMP = false>
-__global__ __launch_bounds__(NW * 64, (BARO && NW * R <= 64) ? 4 : 1) void k_sweep_q(Grid g, const float* __restrict__ psi_in,
-        float* __restrict__ psi_out, const float* __restrict__ base, const float* __restrict__ f,
-        float* __restrict__ res, const MemberState* __restrict__ st, float alpha, int T, int exact_only,
-        unsigned long long* __restrict__ stamps)
+template <int NW, int R>
+__device__ __forceinline__ TileGeom make_geom(const Grid& g, int T, int bx, int by, int m)
 {
-    __shared__ float edge[2][2][NW][64];
-    __shared__ int vote[NW];
-    const int m = blockIdx.z;
-    const MemberState* member = st ? st + m : nullptr;
     constexpr int H = NW * R;
     TileGeom tg;
     tg.lane = threadIdx.x & 63;
     tg.w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform, and known to be
-    tg.x0 = (int)blockIdx.x * (64 - 2 * T) - T;
-    tg.y0 = (int)blockIdx.y * (H - 2 * T) - T;
+    tg.x0 = bx * (64 - 2 * T) - T;
+    tg.y0 = by * (H - 2 * T) - T;
     tg.gx = tg.x0 + tg.lane;
     tg.gy0 = tg.y0 + tg.w * R;
     tg.col_in = tg.gx >= 0 && tg.gx < g.nx;
     tg.col_int = tg.gx >= 1 && tg.gx <= g.nx - 2;
     tg.vx = (tg.lane >= T || tg.x0 <= 0) && (tg.lane < 64 - T || tg.x0 + 63 >= g.nx - 1);
+    tg.inner = tg.x0 >= 1 && tg.x0 + 63 <= g.nx - 2 && tg.y0 >= 1 && tg.y0 + H - 1 <= g.ny - 2;
     tg.mo = (size_t)m * g.plane;
     tg.ks = (size_t)g.members * g.plane;
     tg.stamps = nullptr;
+    return tg;
+}
+
+// (HIP's second launch bound is waves per SIMD: 4 keeps the kernels at 128 VGPRs, i.e. two workgroups per CU.)
+// A tile the optimistic body rejects is redone by the exact body: in this same workgroup for the plain variant; the
+// residual-writing variant (one launch per check) only APPENDS the tile to `redo` ([0] = count, then tile numbers) and
+// k_sweep_q_redo, launched right behind it, walks that list -- with both bodies inlined the residual-writing kernel
+// spilled to scratch, and a kernel that uses scratch is throttled at dispatch (158 us for 4 iterations against 105 us
+// for 6 of the plain variant, profiles/r02).
+template <int NW, int R, bool WRITE_R, bool BARO, bool ALPHA1, bool STAMP = false>
+__global__ __launch_bounds__(NW * 64, (BARO || NW * R < 64) ? 4 : 1) void k_sweep_q(Grid g, const float* __restrict__ psi_in,
+        float* __restrict__ psi_out, const float* __restrict__ base, const float* __restrict__ f,
+        float* __restrict__ res, const MemberState* __restrict__ st, float alpha, int T, int exact_only,
+        int* __restrict__ redo, unsigned long long* __restrict__ stamps)
+{
+    __shared__ float edge[2][2][NW][64];
+    __shared__ int vote[NW];
+    const int m = blockIdx.z;
+    const MemberState* member = st ? st + m : nullptr;
+    TileGeom tg = make_geom<NW, R>(g, T, (int)blockIdx.x, (int)blockIdx.y, m);
     if constexpr (STAMP) {
         tg.stamps = stamps + 32 * ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
         stamp<STAMP>(tg, 0);                              // workgroup started
@@ -350,12 +540,41 @@ __global__ __launch_bounds__(NW * 64, (BARO && NW * R <= 64) ? 4 : 1) void k_swe
             tg.stamps[7] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |
                            ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);
     }
-    if (!exact_only && sweep_tile<NW, R, WRITE_R, BARO, true, STAMP>(g, tg, edge, vote, psi_in, psi_out, base, f, res, alpha, T, member)) {
-        stamp<STAMP>(tg, 6);
-        return;
+    if (!exact_only) {
+        const bool done = tg.inner
+            ? fast_tile<NW, R, WRITE_R, BARO, ALPHA1, true, STAMP>(g, tg, edge, vote, psi_in, psi_out, base, f, res, alpha, T, member)
+            : fast_tile<NW, R, WRITE_R, BARO, ALPHA1, false, STAMP>(g, tg, edge, vote, psi_in, psi_out, base, f, res, alpha, T, member);
+        if (done) {
+            stamp<STAMP>(tg, 6);
+            return;
+        }
     }
-    sweep_tile<NW, R, WRITE_R, BARO, false, STAMP>(g, tg, edge, vote, psi_in, psi_out, base, f, res, alpha, T, member);
+    if constexpr (WRITE_R) {
+        if (threadIdx.x == 0) {
+            const int slot = atomicAdd(redo, 1);
+            redo[1 + slot] = (int)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+        }
+    } else {
+        exact_tile<NW, R, WRITE_R, BARO>(g, tg, edge, psi_in, psi_out, base, f, res, alpha, T, member);
+    }
     stamp<STAMP>(tg, 6);
+}
+
+// the tiles a residual-writing launch left to the exact body (usually none: the grid then finds count == 0 and ends)
+template <int NW, int R, bool BARO>
+__global__ __launch_bounds__(NW * 64) void k_sweep_q_redo(Grid g, const float* __restrict__ psi_in, float* __restrict__ psi_out,
+        const float* __restrict__ base, const float* __restrict__ f, float* __restrict__ res,
+        const MemberState* __restrict__ st, float alpha, int T, const int* __restrict__ redo, int ntx, int nty)
+{
+    __shared__ float edge[2][2][NW][64];
+    const int count = redo[0];
+    for (int i = blockIdx.x; i < count; i += gridDim.x) {
+        const int id = redo[1 + i];
+        const int bx = id % ntx, by = (id / ntx) % nty, m = id / (ntx * nty);
+        const TileGeom tg = make_geom<NW, R>(g, T, bx, by, m);
+        exact_tile<NW, R, true, BARO>(g, tg, edge, psi_in, psi_out, base, f, res, alpha, T, st ? st + m : nullptr);
+        __syncthreads();                                  // the edge rows are reused by the next tile
+    }
 }
 
 // validation kernel for the quotient identity: n pairs per thread drawn from a counter-based generator
@@ -397,7 +616,15 @@ __global__ __launch_bounds__(256) void k_quotient_check(unsigned long long seed,
             if (__builtin_fabsf(t) >= lo && __builtin_fabsf(t) <= hi) a = t;
         }
         const float want = a / d;
-        const float got = quotient_q2(a, -d, quotient_y1(d));
+        // the scalar form, and the packed form (v_pk_mul/fma_f32) in either half of the register pair
+        float got;
+        if (k & 2) {
+            const f2 g2 = quotient_q2(f2{a, (k & 4) ? a : 1.5f}, f2{-d, -d}, f2{quotient_y1(d), quotient_y1(d)});
+            const f2 h2 = quotient_q2(f2{1.25f, a}, f2{-d, -d}, f2{quotient_y1(d), quotient_y1(d)});
+            got = (k & 4) ? g2.x : h2.y;
+        } else {
+            got = quotient_q2(a, -d, quotient_y1(d));
+        }
         if (__builtin_bit_cast(unsigned, want) != __builtin_bit_cast(unsigned, got)) {
             if (bad == 0 && atomicAdd(mismatches + 1, 1ull) == 0) { first_bad[0] = a; first_bad[1] = d; }
             ++bad;
@@ -408,34 +635,46 @@ __global__ __launch_bounds__(256) void k_quotient_check(unsigned long long seed,
 
 template <int NW, int R, bool BARO>
 static void launch_q_cfg(const Grid& g, const float* psi_in, float* psi_out, const float* base, const float* f,
-                         float* res, const MemberState* st, float alpha, int T, int exact_only, hipStream_t s)
+                         float* res, const MemberState* st, float alpha, int T, int exact_only, int* redo, hipStream_t s)
 {
     constexpr int H = NW * R;
     dim3 grid((g.nx - 1 + (64 - 2 * T) - 1) / (64 - 2 * T), (g.ny - 1 + (H - 2 * T) - 1) / (H - 2 * T), g.members);
-    if (res)
-        hipLaunchKernelGGL((k_sweep_q<NW, R, true, BARO>), grid, dim3(NW * 64), 0, s, g, psi_in, psi_out, base, f, res, st, alpha, T, exact_only, (unsigned long long*)nullptr);
-    else
-        hipLaunchKernelGGL((k_sweep_q<NW, R, false, BARO>), grid, dim3(NW * 64), 0, s, g, psi_in, psi_out, base, f, res, st, alpha, T, exact_only, (unsigned long long*)nullptr);
+    const bool a1 = alpha == 1.0f;     // the protocol's damping: 1.0f * x is x, the multiply is not issued
+#define Q_LAUNCH(WR, A1) hipLaunchKernelGGL((k_sweep_q<NW, R, WR, BARO, A1>), grid, dim3(NW * 64), 0, s, g, psi_in, psi_out, base, f, res, st, alpha, T, exact_only, redo, (unsigned long long*)nullptr)
+    if (res) {
+        (void)hipMemsetAsync(redo, 0, sizeof(int), s);
+        if (a1) Q_LAUNCH(true, true); else Q_LAUNCH(true, false);
+        hipLaunchKernelGGL((k_sweep_q_redo<NW, R, BARO>), dim3(exact_only ? 1024 : 64), dim3(NW * 64), 0, s, g, psi_in, psi_out, base, f, res, st,
+                           alpha, T, (const int*)redo, (int)grid.x, (int)grid.y);
+    }
+    else { if (a1) Q_LAUNCH(false, true); else Q_LAUNCH(false, false); }
+#undef Q_LAUNCH
+}
+
+size_t sweep_q_redo_ints(const Grid& g)
+{
+    // one slot per tile of the densest tiling launch_sweep_q admits (tile steps >= 16 columns, >= 8 rows), plus the count
+    return (size_t)g.members * ((g.nx + 15) / 16) * ((g.ny + 7) / 8) + 1;
 }
 
 void launch_sweep_q(const Grid& g, const float* psi_in, float* psi_out, const float* base, const float* f,
                     float* res, const MemberState* st, float alpha, int T, bool barotropic, const SweepOpts& o,
-                    SweepDesc* desc, hipStream_t s)
+                    int* redo, SweepDesc* desc, hipStream_t s)
 {
     const int exact_only = o.q_exact_only ? 1 : 0;
-    // (the nine-weight body needs 156 VGPRs at eight rows per lane -- one workgroup per CU; at six it fits
-    // two: 8.9 against 7.1 cases/s on the baroclinic bench workload)
+    // (the nine-weight body needs too many registers at eight rows per lane for two workgroups per CU; at six it fits)
     int cfg = o.tile;
-    if (cfg != 808 && cfg != 806 && cfg != 416) cfg = barotropic ? 808 : 806;
+    if (cfg != 808 && cfg != 806 && cfg != 804) cfg = barotropic ? 808 : 806;
+    if ((cfg / 100) * (cfg % 100) - 2 * T < 8) cfg = 808;           // the tile must keep a useful core
     if (desc) { desc->name = barotropic ? "k_sweep_q<star>" : "k_sweep_q<nine>"; desc->T = T; desc->tile_w = 64; desc->tile_h = (cfg / 100) * (cfg % 100); }
 #define Q_CASE(NW, R) case NW * 100 + R: \
-        if (barotropic) launch_q_cfg<NW, R, true>(g, psi_in, psi_out, base, f, res, st, alpha, T, exact_only, s); \
-        else launch_q_cfg<NW, R, false>(g, psi_in, psi_out, base, f, res, st, alpha, T, exact_only, s); \
+        if (barotropic) launch_q_cfg<NW, R, true>(g, psi_in, psi_out, base, f, res, st, alpha, T, exact_only, redo, s); \
+        else launch_q_cfg<NW, R, false>(g, psi_in, psi_out, base, f, res, st, alpha, T, exact_only, redo, s); \
         break;
     switch (cfg) {
         Q_CASE(8, 8)
         Q_CASE(8, 6)
-        Q_CASE(4, 16)
+        Q_CASE(8, 4)
     }
 #undef Q_CASE
 }

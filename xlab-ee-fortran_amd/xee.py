@@ -13,6 +13,13 @@ import numpy as np
 
 _HERE = Path(__file__).resolve().parent
 
+__all__ = ["Ensemble", "XeeError", "lib", "lib_path", "device_count", "set_default_option", "reset_default_options",
+           "profiles", "cal_coe", "do_elliptic", "solve_elliptic", "solver_coefficients", "residual_norm", "cal_eta", "cal_uw",
+           "integrate_weight_B", "cal_sum_Qeta", "cal_wtheta", "rhs_thermal", "rhs_from_B", "rhs_momentum", "fd_stencil",
+           "exchange_conversion", "diagnose_case", "CaseRecord", "RECORD_DTYPE", "Timing", "FIELDS", "FD_STENCILS",
+           "BAROTROPIC", "BAROCLINIC", "SOLVE_DEFAULT", "SOLVE_SINGLE_STEP", "SOLVE_KEEP_PSI", "SOLVE_TRACE",
+           "quotient_selfcheck", "m2_from_C", "theta_tendency", "relative_theta", "theta_anomaly_update"]
+
 BAROTROPIC, BAROCLINIC = 0, 1
 SOLVE_DEFAULT, SOLVE_SINGLE_STEP, SOLVE_KEEP_PSI, SOLVE_TRACE = 0, 1, 2, 4
 
@@ -46,7 +53,7 @@ assert RECORD_DTYPE.itemsize == 128 and C.sizeof(CaseRecord) == 128
 
 class Timing(C.Structure):
     _fields_ = [("solve_ms", C.c_double), ("sweep_ms", C.c_double), ("sweep_launches", C.c_int64),
-                ("iterations", C.c_int64), ("check_launches", C.c_int64)]
+                ("iterations", C.c_int64), ("check_launches", C.c_int64), ("redo_tiles", C.c_int64)]
 
 
 _lib = None
