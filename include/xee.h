@@ -169,6 +169,11 @@ int xee_fd_stencil(int which, const float *from, float *to, const float *ra, con
  * this entry is a documented fix, not a parity target.  bndconv (nr-1,2); *sum accumulated sequentially. */
 int xee_exchange_conversion(const float *rpsi, const float *rchi, const float *rhoC, const float *ra,
                             const float *za, const float *rho, float *bndconv, float *sum, int nr, int nz);
+/* ... and exactly as the legacy program computes it, truncation included (r = int((ra(i)+ra(i+1))/2), dr = int(ra(2)-ra(1)),
+ * dz = int(za(2)-za(1)), :1146-1152): bit-identical to the reference's bndconv files and sums (pinned against the legacy
+ * binary, tests/test_oracle_legacy_chain.py); only meaningful on domains measured in units much smaller than dr, dz. */
+int xee_exchange_conversion_legacy(const float *rpsi, const float *rchi, const float *rhoC, const float *ra,
+                                   const float *za, const float *rho, float *bndconv, float *sum, int nr, int nz);
 
 /* Stage II of the legacy TENDENCY mode (src/old-diagnose/diagnose.f90:462-518): forecast of the thermal field
  * between the two inversions.  Grids: A (nr-1,nz), B (nr-1,nz-1), C (nr,nz-1), packed, i fastest.
@@ -184,6 +189,16 @@ int xee_relative_theta(const float *dtheta_dz_A, const float *dtheta_dr_C, const
 int xee_theta_anomaly_update(float *theta_B, float testing_dt, float *rhoB_B, float *rhoA_A, float *rhoB_C,
                              float *b_anomaly_B, float *solver_b_anomaly_B, const float *ra, const float *za,
                              const float *rcuva, const float *rho, int nr, int nz);
+
+/* replaces the staggered averages of the legacy program's input planes, src/old-diagnose/diagnose.f90:329-354:
+ * rhoA_A (nr-1,nz), rhoB_C (nr,nz-1), rhoB_B (nr-1,nz-1, = b_basic_B :348), rhoC_C (nr,nz-1). */
+int xee_legacy_averages(const float *rhoA_in, const float *rhoB_in, const float *rhoC_in, float *rhoA_A, float *rhoB_C,
+                        float *rhoB_B, float *rhoC_C, int nr, int nz);
+/* replaces :383-387, JJ_B = Q / (Cp * exner(j)) on B cells (the field the program writes as J-B.bin) */
+int xee_JJ_B(const float *Q_B, const float *exner, float *JJ_B, int nr, int nz);
+/* elementwise fp32 sum of two packed fields (f = RHS_rpsi_thm + RHS_rpsi_mom :456, solver_b_basic + solver_b_anomaly :572,
+ * the chi sums of :736-737) */
+int xee_add_fields(const float *a, const float *b, float *out, size_t n);
 
 /* replaces the m2 integration, src/old-diagnose/diagnose.f90:359-380, in its INTENDED form (the legacy lines read
  * m2(0,j) and use stale loop indices in the first column): m2(1,j) from its own row, then
@@ -278,6 +293,10 @@ int xee_ensemble_forcing_thermal(xee_ensemble_t *ens);
 int xee_ensemble_forcing_zero(xee_ensemble_t *ens);
 /* solver coefficients (K1) then the 9-point stencil (K2) for the chosen operator variant */
 int xee_ensemble_assemble(xee_ensemble_t *ens, int variant);
+/* the 9-point stencil (K2) from the solver coefficients CURRENTLY held in XEE_F_SOLVER_A / _B / _C (uploaded, or left by
+ * a previous assemble): what the legacy sweep needs for L(A, B0+dB, C) (old-diagnose/diagnose.f90:572) and L(A, 0, C)
+ * (:553).  use_b == 0 takes solverB_B = 0. */
+int xee_ensemble_assemble_solver(xee_ensemble_t *ens, int use_b);
 /* strf := bc_init_in, then solve_elliptic on every member; per-member results in the records */
 int xee_ensemble_solve(xee_ensemble_t *ens, int max_iter, int check_step, int converge_time,
                        int lost_rate, float strategy_r1, float strategy_r2, float alpha, int flags);

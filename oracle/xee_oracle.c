@@ -535,16 +535,20 @@ void orc_f_from_B(const float *b_B, float *f_O, int nr, int nz)
 }
 
 /* src/old-diagnose/diagnose.f90:1143-1174 with real (not integer) r, dr, dz.  parity unpinned. */
-float orc_exchange_conversion(const float *rpsi, const float *rchi, const float *rhoC,
-                              float *bndconv, const float *ra, const float *za,
-                              const float *rho, int nr, int nz)
+static float exchange_conversion_impl(const float *rpsi, const float *rchi, const float *rhoC,
+                                      float *bndconv, const float *ra, const float *za,
+                                      const float *rho, int nr, int nz, int legacy_int)
 {
     float sum = 0.0f;
+    /* legacy_int: `integer :: i, r, dr, dz` (:1146) -- the assignments truncate toward zero, the mixed-mode
+     * expressions convert back to real */
     float dz = za[1] - za[0];
     float dr = ra[1] - ra[0];
+    if (legacy_int) { dz = (float)(int)dz; dr = (float)(int)dr; }
     const int t = nz - 1;
     for (int i = 0; i < nr - 1; ++i) {
         float r = (ra[i] + ra[i + 1]) / 2.0f;
+        if (legacy_int) r = (float)(int)r;
         float bot = ((rhoC[IDX(i, 0, nr)] + rhoC[IDX(i + 1, 0, nr)]) / (2.0f * rho[0]))
                     * (((rpsi[IDX(i, 0, nr)] + rpsi[IDX(i + 1, 0, nr)]) / 2.0f)
                            * ((rchi[IDX(i, 1, nr)] + rchi[IDX(i + 1, 1, nr)] - rchi[IDX(i, 0, nr)] - rchi[IDX(i + 1, 0, nr)]) / (2.0f * dz))
@@ -562,6 +566,22 @@ float orc_exchange_conversion(const float *rpsi, const float *rchi, const float 
         sum = sum - (top - bot) * r * dr;
     }
     return sum;
+}
+
+float orc_exchange_conversion(const float *rpsi, const float *rchi, const float *rhoC,
+                              float *bndconv, const float *ra, const float *za,
+                              const float *rho, int nr, int nz)
+{
+    return exchange_conversion_impl(rpsi, rchi, rhoC, bndconv, ra, za, rho, nr, nz, 0);
+}
+
+/* the same as the legacy program really computes it: r, dr, dz declared INTEGER (:1146).  Pinned against the legacy
+ * binary on a metre-sized domain (tests/test_oracle_legacy_chain.py); on a unit domain r = 0 and the value is Inf/NaN. */
+float orc_exchange_conversion_legacy(const float *rpsi, const float *rchi, const float *rhoC,
+                                     float *bndconv, const float *ra, const float *za,
+                                     const float *rho, int nr, int nz)
+{
+    return exchange_conversion_impl(rpsi, rchi, rhoC, bndconv, ra, za, rho, nr, nz, 1);
 }
 
 /* src/old-diagnose/diagnose.f90:470-479.  `theta0/g0 * (x) / 2.0` is ((theta0/g0) * x) / 2.0, the sum left to right. */

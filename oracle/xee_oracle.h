@@ -122,6 +122,11 @@ float orc_exchange_conversion(const float *rpsi, const float *rchi, const float 
                               float *bndconv, const float *ra, const float *za,
                               const float *rho, int nr, int nz);
 
+/* ... and with the truncation the legacy program really performs (pinned against the legacy binary) */
+float orc_exchange_conversion_legacy(const float *rpsi, const float *rchi, const float *rhoC,
+                                     float *bndconv, const float *ra, const float *za,
+                                     const float *rho, int nr, int nz);
+
 /* ---- legacy TENDENCY mode, Stage II (src/old-diagnose/diagnose.f90:462-518): forecast of the thermal field.
  * parity unpinned against the legacy binary (it has undefined behaviour elsewhere); restated from
  * the source lines cited at each function.  Grids: A (nr-1,nz), B (nr-1,nz-1), C (nr,nz-1). */

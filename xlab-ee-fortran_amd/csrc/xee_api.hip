@@ -570,6 +570,21 @@ int xee_ensemble_assemble(xee_ensemble_t* e, int variant)
     return XEE_OK;
 }
 
+int xee_ensemble_assemble_solver(xee_ensemble_t* e, int use_b)
+{
+    XCHK(use(e));
+    if (!e->sA || !e->sC || (use_b && !e->sB)) return fail(XEE_ERR_INVALID_ARGUMENT, "solver coefficients have not been uploaded / assembled");
+    launch_cal_coe(e->g, e->sA, use_b ? e->sB : nullptr, e->sC, e->coe, e->dr, e->dz, e->stream);
+    XCHK(check_launch("assemble_solver"));
+    XCHK(detect_uniform_planes(e));
+    XCHK(alloc_planes(e, &e->base, 4));
+    launch_base_planes(e->g, e->sA, use_b ? e->sB : nullptr, e->sC, e->base, e->dr, e->dz, e->stream);
+    XCHK(check_launch("base planes"));
+    e->have_base = true;
+    e->base_baro = !use_b;
+    return XEE_OK;
+}
+
 // solve_elliptic, xtt-lib-fortran/elliptic_tools.f90:93-265, for every member at once.
 }  // extern "C"
 

@@ -125,12 +125,14 @@ __global__ __launch_bounds__(256) void k_rhs_momentum(const float* __restrict__ 
 // truncates them and makes its value meaningless -- fixed and documented).
 __global__ void k_exchange_terms(const float* __restrict__ rpsi, const float* __restrict__ rchi,
         const float* __restrict__ rhoC, const float* __restrict__ ra, const float* __restrict__ za,
-        const float* __restrict__ rho, float* __restrict__ bndconv, int nr, int nz)
+        const float* __restrict__ rho, float* __restrict__ bndconv, int nr, int nz, int legacy_int)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nr - 1) return;
-    const float dz = za[1] - za[0];
-    const float r = (ra[i] + ra[i + 1]) / 2.0f;
+    // legacy_int: the reference's `integer :: r, dr, dz` -- assignments truncate toward zero
+    float dz = za[1] - za[0];
+    float r = (ra[i] + ra[i + 1]) / 2.0f;
+    if (legacy_int) { dz = (float)(int)dz; r = (float)(int)r; }
     const int t = nz - 1;
     auto at = [&](const float* f, int ii, int jj) { return f[(size_t)jj * nr + ii]; };
     const float bot = ((at(rhoC, i, 0) + at(rhoC, i + 1, 0)) / (2.0f * rho[0]))
@@ -150,13 +152,15 @@ __global__ void k_exchange_terms(const float* __restrict__ rpsi, const float* __
 }
 
 // sum = sum - (top - bot) * r * dr, sequentially over i (order-exact, one lane; nr-1 terms)
-__global__ void k_exchange_sum(const float* __restrict__ bndconv, const float* __restrict__ ra, float* __restrict__ out, int nr)
+__global__ void k_exchange_sum(const float* __restrict__ bndconv, const float* __restrict__ ra, float* __restrict__ out, int nr, int legacy_int)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const float dr = ra[1] - ra[0];
+    float dr = ra[1] - ra[0];
+    if (legacy_int) dr = (float)(int)dr;
     float s = 0.0f;
     for (int i = 0; i < nr - 1; ++i) {
-        const float r = (ra[i] + ra[i + 1]) / 2.0f;
+        float r = (ra[i] + ra[i + 1]) / 2.0f;
+        if (legacy_int) r = (float)(int)r;
         s = s - (bndconv[(nr - 1) + i] - bndconv[i]) * r * dr;
     }
     out[0] = s;
@@ -267,6 +271,39 @@ __global__ __launch_bounds__(64) void k_m2_from_C(const float* __restrict__ rhoC
 }
 
 }  // namespace
+
+// ---- legacy program, staggered averages of the input planes (src/old-diagnose/diagnose.f90:329-354) -----------------
+// rhoA_A(i,j) = (A(i,j)+A(i+1,j))/2 on A (nr-1,nz);  rhoB_C(i,j) = (B(i,j)+B(i,j+1))/2 and rhoC_C likewise on C (nr,nz-1);
+// rhoB_B = the four-cell average /4 on B (nr-1,nz-1)
+__global__ __launch_bounds__(256) void k_legacy_averages(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ Cc,
+        float* __restrict__ rhoA_A, float* __restrict__ rhoB_C, float* __restrict__ rhoB_B, float* __restrict__ rhoC_C, int nr, int nz)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+    if (i >= nr || j >= nz) return;
+    auto at = [&](const float* f, int ii, int jj) { return f[(size_t)jj * nr + ii]; };
+    if (i < nr - 1) rhoA_A[(size_t)j * (nr - 1) + i] = (at(A, i, j) + at(A, i + 1, j)) / 2.0f;
+    if (j < nz - 1) {
+        rhoB_C[(size_t)j * nr + i] = (at(B, i, j) + at(B, i, j + 1)) / 2.0f;
+        rhoC_C[(size_t)j * nr + i] = (at(Cc, i, j) + at(Cc, i, j + 1)) / 2.0f;
+        if (i < nr - 1)
+            rhoB_B[(size_t)j * (nr - 1) + i] = (at(B, i, j) + at(B, i + 1, j) + at(B, i, j + 1) + at(B, i + 1, j + 1)) / 4.0f;
+    }
+}
+
+// JJ_B(i,j) = Q(i,j) / (Cp * exner(j))   (:383-387)
+__global__ __launch_bounds__(256) void k_JJ_B(const float* __restrict__ Q, const float* __restrict__ exner, float* __restrict__ JJ, int nr, int nz)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+    if (i >= nr - 1 || j >= nz - 1) return;
+    const float Rd = 287.0f, Cv = 5.0f / 2.0f * Rd, Cp = Cv + Rd;      // xtt-lib-fortran/constants.f90:4-7
+    JJ[(size_t)j * (nr - 1) + i] = Q[(size_t)j * (nr - 1) + i] / (Cp * exner[j]);
+}
+
+__global__ __launch_bounds__(256) void k_add_fields(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t n)
+{
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (q < n) out[q] = a[q] + b[q];
+}
 
 extern "C" {
 
@@ -383,8 +420,8 @@ int xee_rhs_momentum(const float* m2_B, const float* F_B, const float* za, const
     return dout.get(rhs_O);
 }
 
-int xee_exchange_conversion(const float* rpsi, const float* rchi, const float* rhoC, const float* ra, const float* za,
-                            const float* rho, float* bndconv, float* sum, int nr, int nz)
+static int exchange_conversion_impl(const float* rpsi, const float* rchi, const float* rhoC, const float* ra, const float* za,
+                                    const float* rho, float* bndconv, float* sum, int nr, int nz, int legacy_int)
 {
     if (!rpsi || !rchi || !rhoC || !ra || !za || !rho || !bndconv || !sum || nr < 3 || nz < 3)
         return record_failure(XEE_ERR_INVALID_ARGUMENT, "xee_exchange_conversion: bad argument");
@@ -394,11 +431,63 @@ int xee_exchange_conversion(const float* rpsi, const float* rchi, const float* r
     TRY(dpsi.put(rpsi, n)); TRY(dchi.put(rchi, n)); TRY(drc.put(rhoC, n));
     TRY(dra.put(ra, nr)); TRY(dza.put(za, nz)); TRY(drho.put(rho, nz));
     TRY(dbnd.put(nullptr, (size_t)(nr - 1) * 2)); TRY(dsum.put(nullptr, 1));
-    hipLaunchKernelGGL(k_exchange_terms, dim3((nr - 1 + 255) / 256), dim3(256), 0, 0, dpsi.p, dchi.p, drc.p, dra.p, dza.p, drho.p, dbnd.p, nr, nz);
-    hipLaunchKernelGGL(k_exchange_sum, dim3(1), dim3(64), 0, 0, dbnd.p, dra.p, dsum.p, nr);
+    hipLaunchKernelGGL(k_exchange_terms, dim3((nr - 1 + 255) / 256), dim3(256), 0, 0, dpsi.p, dchi.p, drc.p, dra.p, dza.p, drho.p, dbnd.p, nr, nz, legacy_int);
+    hipLaunchKernelGGL(k_exchange_sum, dim3(1), dim3(64), 0, 0, dbnd.p, dra.p, dsum.p, nr, legacy_int);
     TRY(finish("xee_exchange_conversion"));
     TRY(dbnd.get(bndconv));
     return dsum.get(sum);
+}
+
+int xee_exchange_conversion(const float* rpsi, const float* rchi, const float* rhoC, const float* ra, const float* za,
+                            const float* rho, float* bndconv, float* sum, int nr, int nz)
+{
+    return exchange_conversion_impl(rpsi, rchi, rhoC, ra, za, rho, bndconv, sum, nr, nz, 0);
+}
+
+int xee_exchange_conversion_legacy(const float* rpsi, const float* rchi, const float* rhoC, const float* ra, const float* za,
+                                   const float* rho, float* bndconv, float* sum, int nr, int nz)
+{
+    return exchange_conversion_impl(rpsi, rchi, rhoC, ra, za, rho, bndconv, sum, nr, nz, 1);
+}
+
+
+int xee_legacy_averages(const float* rhoA_in, const float* rhoB_in, const float* rhoC_in, float* rhoA_A, float* rhoB_C,
+                        float* rhoB_B, float* rhoC_C, int nr, int nz)
+{
+    if (!rhoA_in || !rhoB_in || !rhoC_in || !rhoA_A || !rhoB_C || !rhoB_B || !rhoC_C || nr < 3 || nz < 3)
+        return record_failure(XEE_ERR_INVALID_ARGUMENT, "xee_legacy_averages: bad argument");
+    TRY(need_device());
+    DevBuf dA, dB, dC, oA, oBC, oBB, oCC;
+    const size_t n = (size_t)nr * nz;
+    TRY(dA.put(rhoA_in, n)); TRY(dB.put(rhoB_in, n)); TRY(dC.put(rhoC_in, n));
+    TRY(oA.put(nullptr, (size_t)(nr - 1) * nz)); TRY(oBC.put(nullptr, (size_t)nr * (nz - 1)));
+    TRY(oBB.put(nullptr, (size_t)(nr - 1) * (nz - 1))); TRY(oCC.put(nullptr, (size_t)nr * (nz - 1)));
+    hipLaunchKernelGGL(k_legacy_averages, dim3((nr + 63) / 64, (nz + 3) / 4), dim3(64, 4), 0, 0, dA.p, dB.p, dC.p, oA.p, oBC.p, oBB.p, oCC.p, nr, nz);
+    TRY(finish("xee_legacy_averages"));
+    TRY(oA.get(rhoA_A)); TRY(oBC.get(rhoB_C)); TRY(oBB.get(rhoB_B));
+    return oCC.get(rhoC_C);
+}
+
+int xee_JJ_B(const float* Q_B, const float* exner, float* JJ_B, int nr, int nz)
+{
+    if (!Q_B || !exner || !JJ_B || nr < 3 || nz < 3) return record_failure(XEE_ERR_INVALID_ARGUMENT, "xee_JJ_B: bad argument");
+    TRY(need_device());
+    DevBuf dQ, dex, dJ;
+    TRY(dQ.put(Q_B, (size_t)(nr - 1) * (nz - 1))); TRY(dex.put(exner, nz)); TRY(dJ.put(nullptr, (size_t)(nr - 1) * (nz - 1)));
+    hipLaunchKernelGGL(k_JJ_B, dim3((nr + 62) / 64, (nz + 2) / 4), dim3(64, 4), 0, 0, dQ.p, dex.p, dJ.p, nr, nz);
+    TRY(finish("xee_JJ_B"));
+    return dJ.get(JJ_B);
+}
+
+int xee_add_fields(const float* a, const float* b, float* out, size_t n)
+{
+    if (!a || !b || !out || n == 0) return record_failure(XEE_ERR_INVALID_ARGUMENT, "xee_add_fields: bad argument");
+    TRY(need_device());
+    DevBuf da, db, dout;
+    TRY(da.put(a, n)); TRY(db.put(b, n)); TRY(dout.put(nullptr, n));
+    hipLaunchKernelGGL(k_add_fields, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, da.p, db.p, dout.p, n);
+    TRY(finish("xee_add_fields"));
+    return dout.get(out);
 }
 
 }  // extern "C"

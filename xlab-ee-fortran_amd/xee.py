@@ -16,7 +16,7 @@ _HERE = Path(__file__).resolve().parent
 __all__ = ["Ensemble", "XeeError", "lib", "lib_path", "device_count", "set_default_option", "reset_default_options",
            "profiles", "cal_coe", "do_elliptic", "solve_elliptic", "solver_coefficients", "residual_norm", "cal_eta", "cal_uw",
            "integrate_weight_B", "cal_sum_Qeta", "cal_wtheta", "rhs_thermal", "rhs_from_B", "rhs_momentum", "fd_stencil",
-           "exchange_conversion", "diagnose_case", "CaseRecord", "RECORD_DTYPE", "Timing", "FIELDS", "FD_STENCILS",
+           "exchange_conversion", "legacy_averages", "JJ_B", "add_fields", "diagnose_case", "CaseRecord", "RECORD_DTYPE", "Timing", "FIELDS", "FD_STENCILS",
            "BAROTROPIC", "BAROCLINIC", "SOLVE_DEFAULT", "SOLVE_SINGLE_STEP", "SOLVE_KEEP_PSI", "SOLVE_TRACE",
            "quotient_selfcheck", "m2_from_C", "theta_tendency", "relative_theta", "theta_anomaly_update"]
 
@@ -93,6 +93,7 @@ def lib():
     L.xee_rhs_momentum.argtypes = [_f32p] * 5 + [C.c_int, C.c_int]
     L.xee_fd_stencil.argtypes = [C.c_int] + [_f32p] * 5 + [C.c_int, C.c_int]
     L.xee_exchange_conversion.argtypes = [_f32p] * 7 + [_pf, C.c_int, C.c_int]
+    L.xee_exchange_conversion_legacy.argtypes = [_f32p] * 7 + [_pf, C.c_int, C.c_int]
     vp = C.c_void_p
     L.xee_ensemble_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int]
     L.xee_ensemble_destroy.argtypes = [vp]
@@ -109,6 +110,10 @@ def lib():
     L.xee_ensemble_forcing_thermal.argtypes = [vp]
     L.xee_ensemble_forcing_zero.argtypes = [vp]
     L.xee_ensemble_assemble.argtypes = [vp, C.c_int]
+    L.xee_ensemble_assemble_solver.argtypes = [vp, C.c_int]
+    L.xee_legacy_averages.argtypes = [_f32p] * 7 + [C.c_int, C.c_int]
+    L.xee_JJ_B.argtypes = [_f32p] * 3 + [C.c_int, C.c_int]
+    L.xee_add_fields.argtypes = [_f32p] * 3 + [C.c_size_t]
     L.xee_ensemble_solve.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int]
     L.xee_ensemble_solve_sor.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int]
     L.xee_ensemble_cal_eta.argtypes = [vp]
@@ -286,13 +291,41 @@ def rhs_momentum(m2_B, F_B, prof):
     return out
 
 
-def exchange_conversion(rpsi, rchi, rhoC, prof):
+def exchange_conversion(rpsi, rchi, rhoC, prof, legacy_int=False):
+    """old-diagnose/diagnose.f90:1143-1174 -> (bndconv (2, nr-1), sum); legacy_int reproduces the reference's
+    INTEGER r, dr, dz (:1146), default is the documented fix with real metric factors."""
     nz, nr = rpsi.shape
     bnd = np.zeros((2, nr - 1), np.float32)
     s = C.c_float()
-    _chk(lib().xee_exchange_conversion(_a(rpsi), _a(rchi), _a(rhoC), prof["ra"], prof["za"], prof["rho"], bnd,
+    fn = lib().xee_exchange_conversion_legacy if legacy_int else lib().xee_exchange_conversion
+    _chk(fn(_a(rpsi), _a(rchi), _a(rhoC), prof["ra"], prof["za"], prof["rho"], bnd,
                                        C.byref(s), nr, nz))
     return bnd, np.float32(s.value)
+
+
+def legacy_averages(A, B, Cc):
+    """old-diagnose/diagnose.f90:329-354 -> (rhoA_A (nz,nr-1), rhoB_C (nz-1,nr), rhoB_B (nz-1,nr-1), rhoC_C (nz-1,nr))."""
+    nz, nr = A.shape
+    out = (np.zeros((nz, nr - 1), np.float32), np.zeros((nz - 1, nr), np.float32), np.zeros((nz - 1, nr - 1), np.float32),
+           np.zeros((nz - 1, nr), np.float32))
+    _chk(lib().xee_legacy_averages(_a(A), _a(B), _a(Cc), *out, nr, nz))
+    return out
+
+
+def JJ_B(Q_B, exner):
+    """old-diagnose/diagnose.f90:383-387 -> Q / (Cp exner) on B cells."""
+    nzm, nrm = Q_B.shape
+    out = np.zeros((nzm, nrm), np.float32)
+    _chk(lib().xee_JJ_B(_a(Q_B), _a(exner), out, nrm + 1, nzm + 1))
+    return out
+
+
+def add_fields(a, b):
+    a, b = _a(a), _a(b)
+    assert a.shape == b.shape
+    out = np.zeros_like(a)
+    _chk(lib().xee_add_fields(a, b, out, a.size))
+    return out
 
 
 # ---- Tier 2: device-resident ensemble ---------------------------------------------------------
@@ -424,6 +457,10 @@ class Ensemble:
 
     def assemble(self, variant):
         _chk(lib().xee_ensemble_assemble(self._h, variant))
+
+    def assemble_solver(self, use_b):
+        """cal_coe from the solver coefficients currently in SOLVER_A/_B/_C (use_b False: solverB_B = 0)."""
+        _chk(lib().xee_ensemble_assemble_solver(self._h, 1 if use_b else 0))
 
     def solve(self, max_iter, r1, r2, alpha, check_step=100, converge_time=10, lost_rate=5, flags=0):
         _chk(lib().xee_ensemble_solve(self._h, int(max_iter), check_step, converge_time, lost_rate,
