@@ -240,6 +240,32 @@ def main():
 
     from xlab_ee_fortran_amd import ensemble_dp as dp
 
+    # the record gather runs through libxee's own C-ABI communicator (RCCL ncclAllGather); torch.distributed only
+    # carries the 128-byte rendezvous id, the barrier and the max-over-ranks of the timing
+    comm, gather_via = None, "none (1 rank)"
+    if world > 1 and backend == "nccl":
+        def bcast(b):
+            t = torch.zeros(xee.COMM_ID_BYTES, dtype=torch.uint8, device=coll_dev)
+            if rank == 0:
+                t = torch.frombuffer(bytearray(b), dtype=torch.uint8).to(coll_dev)
+            dist.broadcast(t, src=0)
+            return bytes(t.cpu().numpy().tobytes())
+        try:
+            comm = dp.make_comm(xee, world, rank, local_rank, bcast)
+            gather_via = "xee_gather_scalars (RCCL ncclAllGather behind the C-ABI)"
+        except Exception as exc:      # never lose the measurement to the collective's set-up: fall back, and say so
+            comm, gather_via = None, f"torch.distributed all_gather (xee_comm_create failed: {exc})"
+        flags = [None] * world
+        dist.all_gather_object(flags, comm is not None)
+        if not all(flags):
+            if comm is not None:
+                comm.close()
+            comm = None
+            if gather_via.startswith("xee_"):
+                gather_via = "torch.distributed all_gather (another rank could not create its xee_comm)"
+    elif world > 1:
+        gather_via = f"torch.distributed all_gather over {backend} (rehearsal)"
+
     def step():
         ens.forcing_from_B()                   # A7
         ens.assemble(xee.BAROCLINIC if operator == "BAROCLINIC" else xee.BAROTROPIC)   # K1 + K2
@@ -247,7 +273,7 @@ def main():
         ens.cal_eta()                          # K5
         rec = ens.ee_scalars()                 # K8
         if world > 1:                          # the one collective of the path: scalar records over RCCL
-            rec = dp.gather_records(rec, world * M, world, rank, device=coll_dev)
+            rec = dp.gather_records(rec, world * M, world, rank, device=coll_dev, comm=comm)
         return rec
 
     def fence():
@@ -309,7 +335,7 @@ def main():
                                    + ("BAROCLINIC (full B)" if operator == "BAROCLINIC" else "BAROTROPIC (B=0)"),
                        "nr": nr, "nz": nz, "members_per_gpu": M, "max_iter": args.max_iter,
                        "solver": "damped Jacobi, bit-identical to the reference (SURVEY.md finding 1)",
-                       "parallelism": f"ensemble-dp{world}"},
+                       "parallelism": f"ensemble-dp{world}", "record_gather": gather_via},
             "iterations_per_s": world * M * iters / dt,
             "point_updates_per_s": world * M * iters * interior / dt,
             "all_cases_ran_to_max_iter": bool(len(rec) == world * M and np.all(rec["iters"] == args.max_iter)),
@@ -343,6 +369,8 @@ def main():
             out["cpu_baseline"], out["cpu_baseline_all_cores"] = cpu_baselines(nr, nz, args.max_iter, args.cpu_sample_iters)
         print(json.dumps(out), flush=True)
     ens.close()
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -323,6 +323,23 @@ int xee_ensemble_time_sweeps(xee_ensemble_t *ens, int iters, int variant, float 
 int xee_quotient_selfcheck(int device, uint64_t seed, int blocks, int per_thread, int d_exp_lo, int d_exp_hi,
                            uint64_t *mismatches, float *first_bad /* 2: a, d of one failing pair */);
 
+/* ---------------------------------------------------------------------------------------------
+ * Multi-GPU: one process per GPU, cases partitioned in consecutive blocks, ONE collective -- an all-gather of the
+ * 128-byte case records over RCCL/xGMI (SURVEY.md 8b "xee_gather_scalars", 8e "ncclAllGather").  The reference has no
+ * counterpart (it is a single-threaded CPU program); this is how an ensemble host collects the per-case scalars.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct xee_comm xee_comm_t;
+#define XEE_COMM_ID_BYTES 128
+/* rank 0 makes the rendezvous id and hands its XEE_COMM_ID_BYTES bytes to the other ranks (file, broadcast, ...) */
+int xee_comm_unique_id(char *id);
+/* collective over all ranks: joins the communicator on `device` (-1: the current device) */
+int xee_comm_create(xee_comm_t **comm, const char *id, int rank, int world, int device);
+int xee_comm_rank(const xee_comm_t *comm, int *rank, int *world);
+int xee_comm_destroy(xee_comm_t *comm);
+/* collective: every rank contributes per_rank records (pad a short block with case_id = -1) and receives the
+ * world * per_rank records of all ranks, ordered by rank, in `all` (host memory on both sides) */
+int xee_gather_scalars(xee_comm_t *comm, const xee_case_record_t *local, int per_rank, xee_case_record_t *all);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,3 +74,23 @@ def test_bench_two_ranks_rehearsal_over_gloo():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["members_per_gpu"] == 3 and d["all_cases_ran_to_max_iter"] is True
     assert d["value"] > 0 and d["scaling"] == "weak" and d["config"]["parallelism"] == "ensemble-dp2"
+
+
+def test_cabi_record_gather_on_one_rank():
+    """xee_comm_* / xee_gather_scalars (RCCL behind the C-ABI) on the one GPU of this box: a world of one rank goes through
+    ncclCommInitRank and ncclAllGather for real (RCCL refuses two ranks on one device, so the N > 1 exchange itself is
+    covered by the gloo tests and exercised by the driver's multi-GPU run)."""
+    import numpy as np
+    sys.path.insert(0, str(ROOT))
+    import xee_pkg
+    xee = xee_pkg.load()
+    uid = xee.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    comm = xee.Comm(uid, 0, 1)
+    rec = np.zeros(5, xee.RECORD_DTYPE)
+    rec["case_id"] = np.arange(5) + 10
+    rec["efficiency"] = np.float32(0.25) * np.arange(5, dtype=np.float32)
+    rec["scalars"][:, 3] = 7.0
+    out = comm.gather(rec, 8)
+    assert len(out) == 8 and out[:5].tobytes() == rec.tobytes() and np.all(out["case_id"][5:] == -1)
+    comm.close()

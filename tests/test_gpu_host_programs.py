@@ -3,6 +3,7 @@
   * oracle/_ref/diagnose_dropin -- the REFERENCE program itself (main.f90 + its support modules)
     with only `module elliptic_tools` swapped for fortran/elliptic_tools.f90 -> libxee: the
     source-level drop-in proof (built in this container; the binary travels to the GPU box)."""
+import os
 import re
 import subprocess
 from pathlib import Path
@@ -106,3 +107,56 @@ def test_efficiency_txt_extension(tmp_path):
         assert np.float32(raw[label][1]).tobytes() == np.float32(sqe / sq).tobytes()
     eff = T.read_efficiency(str(tmp_path / "efficiency.txt"))
     assert eff["internal"] == pytest.approx(float(np.float32(H.cal_sum_Qeta(Q, want["BAROTROPIC"]["eta"], prof) / sq)), rel=1e-6)
+
+
+# ---- ensemble / case-list mode of the Fortran host (bin/xee-ensemble) ---------------------------------------------
+
+ENSEMBLE = ROOT / "xlab-ee-fortran_amd" / "bin" / "xee-ensemble"
+
+
+@pytest.mark.parametrize("force_gather", [False, True])
+def test_fortran_ensemble_host_equals_single_case_runs(force_gather, tmp_path):
+    """N cases in ONE device ensemble (members stop on their own criterion) write, per case, byte for byte the files
+    xee-diagnose writes when run on that case alone; the gathered records land in ensemble_summary.txt.  With
+    XEE_ENSEMBLE_FORCE_GATHER the one-rank run goes through xee_comm_* / xee_gather_scalars (RCCL) for real."""
+    assert ENSEMBLE.exists() and HOST.exists(), "build them: make -C xlab-ee-fortran_amd fortran"
+    nr, nz, N = 96, 64, 5
+    mode = ("DYNAMIC_EFFICIENCY", "CYLINDRICAL", "DENSITY_NORMAL", "BARO_ALL")
+    cfg = dict(mode=mode, domain=(0.0, 2.0e5, 0.0, 1.5e4), r1=1.0, r2=5e-3, alpha=1.0, max_iter=20000)
+    rb = np.linspace(0, 1, nr - 1)[None, :]
+    zb = np.linspace(0, 1, nz - 1)[:, None]
+    Q = np.exp(-((rb - 0.3) / 0.1) ** 2 - ((zb - 0.5) / 0.2) ** 2).astype(np.float32)
+    dirs, singles = [], []
+    for k in range(N):
+        A, B, Cc, bc = H.rich_inputs(nr, nz, seed=60 + k)
+        g = {"in_A": A, "in_B": B, "in_C": Cc, "in_bc": bc}
+        g = type("G", (dict,), {"files": list(g)})(g)
+        d = tmp_path / f"case{k}"; d.mkdir()
+        s = tmp_path / f"single{k}"; s.mkdir()
+        run_program(HOST, s, g, cfg, q=Q)                            # the single-case reference run (also leaves the inputs)
+        for name in ("A", "B", "C", "bc_init", "Q"):
+            (d / f"{name}.bin").write_bytes((s / f"{name}.bin").read_bytes())
+        dirs.append(d); singles.append(s)
+    lines = ["-".join(mode), "%.9e %.9e %.9e %.9e" % cfg["domain"], f"{nr} {nz}",
+             "%.9e %.9e %d %.9e // criteria" % (cfg["r1"], cfg["r2"], cfg["max_iter"], cfg["alpha"]), str(N)] + [str(d) for d in dirs]
+    (tmp_path / "ensemble.txt").write_text("\n".join(lines) + "\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "XEE_RANK", "XEE_WORLD")}
+    if force_gather:
+        env["XEE_ENSEMBLE_FORCE_GATHER"] = "1"
+    with open(tmp_path / "ensemble.txt") as fin:
+        p = subprocess.run([str(ENSEMBLE)], stdin=fin, cwd=tmp_path, capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    iters = set()
+    for k in range(N):
+        for fn in ("solver_a-sA.bin", "solver_b-B.bin", "solver_c-sC.bin", "eta-[BAROTROPIC]-A.bin", "rchi-[BAROTROPIC]-O.bin",
+                   "eta-[BAROCLINIC]-A.bin", "rchi-[BAROCLINIC]-O.bin"):
+            assert (dirs[k] / fn).read_bytes() == (singles[k] / fn).read_bytes(), (k, fn)
+    summary = [ln.split() for ln in (tmp_path / "ensemble_summary.txt").read_text().splitlines() if ln.strip() and ln.split()[0].isdigit()]
+    assert [int(r[0]) for r in summary] == list(range(N))
+    for k, r in enumerate(summary):
+        eff = T.read_efficiency_raw(str(singles[k] / "efficiency.txt"))
+        assert float(r[6]) == pytest.approx(eff["eta [L(B=B0dB) = B0]     wo/ boundary"][0], rel=1e-8)      # sum_Qeta of the last variant
+        assert float(r[5]) == pytest.approx(eff["sum Q"][0], rel=1e-8)
+        iters.add(int(r[1]))
+    assert len(iters) > 1, "the cases should stop at different iterations"
+    assert not (tmp_path / ".xee_comm_id").exists()

@@ -129,6 +129,43 @@ interface
 
     ! host-array stencils of the two driver programs (quick-tools2.f90:1-85; old-diagnose/diagnose.f90:412-436,
     ! :1143-1174); which = 0..5 in the order d_dz_B2A, d_dz_O2C, d_dr_B2B, d_dr_B2C, d_dr_O2A, d_rcuvdr_O2A
+    function xee_ensemble_set_case_ids(ens, first_case_id) bind(C, name="xee_ensemble_set_case_ids") result(st)
+        import :: c_int, c_ptr
+        type(c_ptr), value :: ens
+        integer(c_int), value :: first_case_id
+        integer(c_int) :: st
+    end function
+
+    ! ---- multi-GPU: one process per GPU, the record gather over RCCL (include/xee.h, xee_comm_* / xee_gather_scalars)
+    function xee_comm_unique_id(id) bind(C, name="xee_comm_unique_id") result(st)
+        import :: c_int, c_char
+        character(kind=c_char), intent(out) :: id(*)          ! XEE_COMM_ID_BYTES = 128
+        integer(c_int) :: st
+    end function
+
+    function xee_comm_create(comm, id, rank, world, device) bind(C, name="xee_comm_create") result(st)
+        import :: c_int, c_ptr, c_char
+        type(c_ptr), intent(out) :: comm
+        character(kind=c_char), intent(in) :: id(*)
+        integer(c_int), value :: rank, world, device
+        integer(c_int) :: st
+    end function
+
+    function xee_comm_destroy(comm) bind(C, name="xee_comm_destroy") result(st)
+        import :: c_int, c_ptr
+        type(c_ptr), value :: comm
+        integer(c_int) :: st
+    end function
+
+    function xee_gather_scalars(comm, local, per_rank, all) bind(C, name="xee_gather_scalars") result(st)
+        import :: c_int, c_ptr, xee_case_record
+        type(c_ptr), value :: comm
+        type(xee_case_record), intent(in) :: local(*)
+        integer(c_int), value :: per_rank
+        type(xee_case_record), intent(out) :: all(*)
+        integer(c_int) :: st
+    end function
+
     function xee_fd_stencil(which, from_dat, to_dat, ra, za, rcuva, nr, nz) bind(C, name="xee_fd_stencil") result(st)
         import :: c_int, c_float
         integer(c_int), value :: which, nr, nz

@@ -13,7 +13,7 @@ import numpy as np
 
 _HERE = Path(__file__).resolve().parent
 
-__all__ = ["Ensemble", "XeeError", "lib", "lib_path", "device_count", "set_default_option", "reset_default_options",
+__all__ = ["Ensemble", "Comm", "comm_unique_id", "COMM_ID_BYTES", "XeeError", "lib", "lib_path", "device_count", "set_default_option", "reset_default_options",
            "profiles", "cal_coe", "do_elliptic", "solve_elliptic", "solver_coefficients", "residual_norm", "cal_eta", "cal_uw",
            "integrate_weight_B", "cal_sum_Qeta", "cal_wtheta", "rhs_thermal", "rhs_from_B", "rhs_momentum", "fd_stencil",
            "exchange_conversion", "legacy_averages", "JJ_B", "add_fields", "diagnose_case", "CaseRecord", "RECORD_DTYPE", "Timing", "FIELDS", "FD_STENCILS",
@@ -127,6 +127,10 @@ def lib():
     L.xee_relative_theta.argtypes = [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int]
     L.xee_theta_anomaly_update.argtypes = [_f32p, C.c_float, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p,
                                            C.c_int, C.c_int]
+    L.xee_comm_unique_id.argtypes = [C.c_char_p]
+    L.xee_comm_create.argtypes = [C.POINTER(vp), C.c_char_p, C.c_int, C.c_int, C.c_int]
+    L.xee_comm_destroy.argtypes = [vp]
+    L.xee_gather_scalars.argtypes = [vp, C.c_void_p, C.c_int, C.c_void_p]
     L.xee_quotient_selfcheck.argtypes = [C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
     _lib = L
@@ -371,6 +375,47 @@ def quotient_selfcheck(seed, blocks, per_thread, d_exp_lo, d_exp_hi, device=-1):
     bad, first = C.c_uint64(), (C.c_float * 2)()
     _chk(lib().xee_quotient_selfcheck(device, seed, blocks, per_thread, d_exp_lo, d_exp_hi, C.byref(bad), first))
     return bad.value, (first[0], first[1])
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """Rank 0: the 128-byte RCCL rendezvous id to hand to the other ranks (xee_comm_unique_id)."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _chk(lib().xee_comm_unique_id(buf))
+    return buf.raw
+
+
+class Comm:
+    """RCCL communicator of the ensemble ranks (one process per GPU) for the record gather, xee_comm_* / xee_gather_scalars."""
+
+    def __init__(self, unique_id, rank, world, device=-1):
+        assert len(unique_id) == COMM_ID_BYTES
+        self.rank, self.world = rank, world
+        self._h = C.c_void_p()
+        _chk(lib().xee_comm_create(C.byref(self._h), unique_id, rank, world, device))
+
+    def gather(self, records, per_rank):
+        """records: this rank's RECORD_DTYPE array (<= per_rank entries); returns the world*per_rank records of all ranks,
+        rank by rank, short blocks padded with case_id = -1."""
+        pad = np.zeros(per_rank, RECORD_DTYPE)
+        pad["case_id"] = -1
+        pad[: len(records)] = records
+        out = np.zeros(self.world * per_rank, RECORD_DTYPE)
+        _chk(lib().xee_gather_scalars(self._h, pad.ctypes.data_as(C.c_void_p), per_rank, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().xee_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Ensemble:
