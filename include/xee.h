@@ -93,6 +93,12 @@ int xee_solve_elliptic(int *max_iter, int check_step, int converge_time, int los
                        float *dat, const float *coe, const float *f, float *workspace,
                        int nx, int ny, int *err, int debug);
 
+/* which sweep kernel this thread's last xee_solve_elliptic launched (name, iterations per launch, tile extent): when the
+ * coe it was handed is bit for bit what this thread's last xee_cal_coe returned, the operator's generating planes are
+ * rebuilt from that call's a, b, c and the solve takes the fast kernel (k_sweep_q); any other coe takes the nine-plane
+ * kernel (k_sweep_tb).  Same results either way. */
+int xee_last_sweep_info(char *name, int name_len, int *T, int *tile_w, int *tile_h);
+
 /* replaces the residual norm inside solve_elliptic, elliptic_tools.f90:193-199, as a stand-alone call:
  * *sum_sq = the sequential fp32 sum (i outer, j inner) of res(i,j)**2 over the interior, bit for bit;
  * *rms = sqrt(sum_sq / ((nx-2)*(ny-2))).  slow_chunks (may be NULL) reports how many 32-term chunks the

@@ -329,3 +329,30 @@ def test_elision_on_off_same_bits():
     assert a["sweep"]["name"] == "k_sweep_tb<elided>" and b["sweep"]["name"] == "k_sweep_tb"
     assert biteq(a["psi"][0], want["psi"])
     assert biteq(a["psi"], b["psi"]) and a["r1"].tobytes() == b["r1"].tobytes()
+
+
+# ---- Tier 1 drop-in: cal_coe -> solve_elliptic takes the fast kernel ------------------------------------------------
+
+@pytest.mark.parametrize("variant", ["BAROTROPIC", "BAROCLINIC"])
+def test_tier1_solve_reuses_cal_coe_for_the_fast_kernel(variant):
+    """The drop-in user's sequence (src/diagnose/diagnose.f90:7,15): cal_coe, then solve_elliptic with that coe.  When the
+    coe handed to the solve is bit for bit what this thread's last cal_coe returned, the solve rebuilds the generating
+    planes and runs k_sweep_q; a coe that differs in one bit takes the nine-plane kernel.  Same bits as the oracle both
+    ways."""
+    nr, nz = 200, 120
+    A, B, Cc, bc = H.rich_inputs(nr, nz, seed=9)
+    prof = H.profiles(nr, nz, 0, 0, (0.0, 2.0e5, 0.0, 1.5e4))
+    sA, sB, sC = H.solver_coefficients(A, B, Cc, prof["rcuva"], prof["rho"])
+    b_use = sB if variant == "BAROCLINIC" else np.zeros_like(sB)
+    f = (-B).astype(np.float32)
+    coe, err = xee.cal_coe(sA, b_use, sC, prof["dr"], prof["dz"], nr, nz)
+    want = H.solve(bc, H.cal_coe(sA, b_use, sC, prof["dr"], prof["dz"], nr, nz), f, 437, 1e-8, -1.0, 0.9)
+    got = xee.solve_elliptic(bc, coe, f, 437, 1e-8, -1.0, 0.9)
+    assert xee.last_sweep_info()["name"] == ("k_sweep_q<nine>" if variant == "BAROCLINIC" else "k_sweep_q<star>")
+    assert biteq(got[0], want[0]) and got[3].tobytes() == want[3].tobytes()
+    coe2 = coe.copy()
+    coe2[60, 100, 4] = np.nextafter(coe2[60, 100, 4], np.float32(0))       # one ulp off in one interior coefficient
+    want2 = H.solve(bc, coe2, f, 437, 1e-8, -1.0, 0.9)
+    got2 = xee.solve_elliptic(bc, coe2, f, 437, 1e-8, -1.0, 0.9)
+    assert xee.last_sweep_info()["kernel"] == "k_sweep_tb"
+    assert biteq(got2[0], want2[0]) and not biteq(got2[0], got[0])

@@ -1066,6 +1066,87 @@ struct Scoped {
 };
 }  // namespace
 
+namespace {
+// What the last xee_cal_coe of this thread produced, kept on the device: the solver coefficients it was given and the
+// nine coefficient planes it returned.  xee_solve_elliptic receives an arbitrary host `coe`; when the one it is handed
+// holds exactly these bits (compared on the device after the upload it needs anyway), the operator's generating planes
+// can be rebuilt from a, b, c and the solve runs k_sweep_q instead of the nine-plane kernel -- the drop-in user
+// (the reference's main.f90: cal_coe, then solve_elliptic with that coe, diagnose.f90:7,15) gets the fast path.
+struct CoeCache {
+    int device = -1, nx = 0, ny = 0;
+    float dx = 0.f, dy = 0.f;
+    size_t plane = 0;
+    float *abc = nullptr, *coe = nullptr;      // 3 + 9 planes
+    bool b_zero = false, valid = false;
+    ~CoeCache() { /* process exit: the runtime may already be gone; leak the two buffers */ }
+};
+thread_local CoeCache g_cc;
+thread_local SweepDesc g_last_tier1_sweep{};
+
+int cache_store(xee_ensemble* e, const float* b_host, float dx, float dy)
+{
+    CoeCache& cc = g_cc;
+    cc.valid = false;
+    if (cc.device != e->device || cc.plane != e->g.plane) {
+        if (cc.abc) hipFree(cc.abc);
+        if (cc.coe) hipFree(cc.coe);
+        cc.abc = cc.coe = nullptr;
+        if (hipMalloc(reinterpret_cast<void**>(&cc.abc), sizeof(float) * 3 * e->g.plane) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&cc.coe), sizeof(float) * 9 * e->g.plane) != hipSuccess) {
+            if (cc.abc) hipFree(cc.abc);
+            cc.abc = cc.coe = nullptr; cc.plane = 0; cc.device = -1;
+            (void)hipGetLastError();
+            return XEE_OK;                       // no cache, no harm: the solve takes the nine-plane kernel
+        }
+        cc.device = e->device; cc.plane = e->g.plane;
+    }
+    const size_t pb = sizeof(float) * e->g.plane;
+    HIPCHK(hipMemcpyAsync(cc.abc, e->sA, pb, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(cc.abc + e->g.plane, e->sB, pb, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(cc.abc + 2 * e->g.plane, e->sC, pb, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(cc.coe, e->coe, 9 * pb, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    cc.nx = e->g.nx; cc.ny = e->g.ny; cc.dx = dx; cc.dy = dy;
+    cc.b_zero = true;                            // b = +0 everywhere: the BAROTROPIC operator (diagnose.f90:6)
+    const size_t nb = (size_t)(cc.nx - 1) * (cc.ny - 1);
+    for (size_t q = 0; q < nb; ++q) {
+        unsigned bits;
+        memcpy(&bits, b_host + q, sizeof bits);
+        if (bits != 0u) { cc.b_zero = false; break; }
+    }
+    cc.valid = true;
+    return XEE_OK;
+}
+
+// after the caller's coe is on the device: is it the cached one?  then build the generating planes
+int cache_try(xee_ensemble* e)
+{
+    const CoeCache& cc = g_cc;
+    if (!cc.valid || cc.device != e->device || cc.nx != e->g.nx || cc.ny != e->g.ny || cc.plane != e->g.plane) return XEE_OK;
+    if (!e->uv_differs) HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->uv_differs), sizeof(unsigned)));
+    launch_coe_compare(e->g, e->coe, cc.coe, e->uv_differs, e->stream);
+    unsigned differs = 1u;
+    HIPCHK(hipMemcpyAsync(&differs, e->uv_differs, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (differs) return XEE_OK;
+    XCHK(alloc_planes(e, &e->base, 4));
+    launch_base_planes(e->g, cc.abc, cc.b_zero ? nullptr : cc.abc + e->g.plane, cc.abc + 2 * e->g.plane, e->base, cc.dx, cc.dy, e->stream);
+    XCHK(check_launch("base planes (Tier 1)"));
+    e->have_base = true;
+    e->base_baro = cc.b_zero;
+    return XEE_OK;
+}
+}  // namespace
+
+int xee_last_sweep_info(char* name, int name_len, int* T, int* tile_w, int* tile_h)
+{
+    if (name && name_len > 0) { strncpy(name, g_last_tier1_sweep.name, (size_t)name_len - 1); name[name_len - 1] = 0; }
+    if (T) *T = g_last_tier1_sweep.T;
+    if (tile_w) *tile_w = g_last_tier1_sweep.tile_w;
+    if (tile_h) *tile_h = g_last_tier1_sweep.tile_h;
+    return XEE_OK;
+}
+
 int xee_cal_coe(const float* a, const float* b, const float* c, float* coe, float dx, float dy, int nx, int ny, int* err)
 {
     if (!a || !b || !c || !coe || !err) return fail(XEE_ERR_INVALID_ARGUMENT, "null argument");
@@ -1087,6 +1168,7 @@ int xee_cal_coe(const float* a, const float* b, const float* c, float* coe, floa
     if (he == hipSuccess) he = hipGetLastError();
     hipFree(aos);
     if (he != hipSuccess) return fail(XEE_ERR_HIP, std::string("xee_cal_coe: ") + hipGetErrorString(he));
+    XCHK(cache_store(e, b, dx, dy));
     *err = 0;                                                   // :58
     return XEE_OK;
 }
@@ -1150,10 +1232,12 @@ int xee_solve_elliptic(int* max_iter, int check_step, int converge_time, int los
     XCHK(xee_ensemble_create(&sc.e, nx, ny, 1, -1));
     xee_ensemble_t* e = sc.e;
     XCHK(upload_coe_aos(e, coe));
+    XCHK(cache_try(e));                                         // this thread's last cal_coe made exactly this coe?
     XCHK(xee_ensemble_upload(e, XEE_F_BC_INIT, 0, 1, dat));
     XCHK(xee_ensemble_upload(e, XEE_F_FORCING, 0, 1, f));
     XCHK(xee_ensemble_solve(e, *max_iter, check_step, converge_time, lost_rate, *strategy_r1, *strategy_r2, alpha,
                             debug == 2 ? XEE_SOLVE_TRACE : XEE_SOLVE_DEFAULT));
+    g_last_tier1_sweep = e->last_sweep;
     XCHK(xee_ensemble_download(e, XEE_F_PSI, 0, 1, dat));
     const xee_case_record_t& r = e->rec[0];
     *err = r.err_bits;

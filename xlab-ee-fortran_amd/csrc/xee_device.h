@@ -96,6 +96,7 @@ struct UniformVals {
     float v[9];      // its value
 };
 void launch_uniform_check(const Grid& g, const float* coe, unsigned* differs /* device, 1 word */, hipStream_t s);
+void launch_coe_compare(const Grid& g, const float* x, const float* y, unsigned* differs /* device, 1 word */, hipStream_t s);
 // T damped-Jacobi iterations in one launch (temporally blocked kernel), 2 <= T <= tb_max_T()
 void launch_sweep_tb(const Grid& g, const float* psi_in, float* psi_out, const float* coe,
                      const float* f, float* res /* residual of the LAST iteration, or nullptr */,

@@ -810,6 +810,27 @@ __global__ __launch_bounds__(256) void k_uniform_check(Grid g, const float* __re
     if (bad) atomicOr(differs, bad);
 }
 
+// do two sets of nine coefficient planes hold the same bits over the interior of every member?
+__global__ __launch_bounds__(256) void k_coe_compare(Grid g, const float* __restrict__ x, const float* __restrict__ y, unsigned* __restrict__ differs)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int j = blockIdx.y * 4 + threadIdx.y;
+    if (i < 1 || i > g.nx - 2 || j < 1 || j > g.ny - 2) return;
+    const size_t o = (size_t)blockIdx.z * g.plane + (size_t)j * g.pitch + i;
+    const size_t ks = (size_t)g.members * g.plane;
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+        bad = bad || __builtin_bit_cast(unsigned, x[k * ks + o]) != __builtin_bit_cast(unsigned, y[k * ks + o]);
+    if (bad) atomicOr(differs, 1u);
+}
+
+void launch_coe_compare(const Grid& g, const float* x, const float* y, unsigned* differs, hipStream_t s)
+{
+    (void)hipMemsetAsync(differs, 0, sizeof(unsigned), s);
+    hipLaunchKernelGGL(k_coe_compare, grid2d(g), kBlk, 0, s, g, x, y, differs);
+}
+
 void launch_uniform_check(const Grid& g, const float* coe, unsigned* differs, hipStream_t s)
 {
     hipMemsetAsync(differs, 0, sizeof(unsigned), s);

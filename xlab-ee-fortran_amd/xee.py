@@ -13,7 +13,7 @@ import numpy as np
 
 _HERE = Path(__file__).resolve().parent
 
-__all__ = ["Ensemble", "Comm", "comm_unique_id", "COMM_ID_BYTES", "XeeError", "lib", "lib_path", "device_count", "set_default_option", "reset_default_options",
+__all__ = ["Ensemble", "Comm", "comm_unique_id", "COMM_ID_BYTES", "XeeError", "lib", "lib_path", "device_count", "set_default_option", "reset_default_options", "last_sweep_info",
            "profiles", "cal_coe", "do_elliptic", "solve_elliptic", "solver_coefficients", "residual_norm", "cal_eta", "cal_uw",
            "integrate_weight_B", "cal_sum_Qeta", "cal_wtheta", "rhs_thermal", "rhs_from_B", "rhs_momentum", "fd_stencil",
            "exchange_conversion", "legacy_averages", "JJ_B", "add_fields", "diagnose_case", "CaseRecord", "RECORD_DTYPE", "Timing", "FIELDS", "FD_STENCILS",
@@ -150,6 +150,16 @@ def device_count():
     n = C.c_int(0)
     _chk(lib().xee_device_count(C.byref(n)))
     return n.value
+
+
+def last_sweep_info():
+    """The sweep kernel this thread's last Tier-1 solve_elliptic launched (xee_last_sweep_info)."""
+    buf = C.create_string_buffer(64)
+    T, tw, th = C.c_int(), C.c_int(), C.c_int()
+    lib().xee_last_sweep_info.argtypes = [C.c_char_p, C.c_int, _pi, _pi, _pi]
+    _chk(lib().xee_last_sweep_info(buf, 64, C.byref(T), C.byref(tw), C.byref(th)))
+    name = buf.value.decode()
+    return {"name": name, "kernel": name.split("<")[0], "T": T.value, "tile": f"{tw.value}x{th.value}"}
 
 
 def set_default_option(key, value):
