@@ -316,6 +316,9 @@ int xee_ensemble_cal_eta(xee_ensemble_t *ens);
 int xee_ensemble_cal_uw(xee_ensemble_t *ens);
 /* sum_Q, sum_Qeta, efficiency from Q and the current eta (order-exact fp32 sums) */
 int xee_ensemble_ee_scalars(xee_ensemble_t *ens);
+/* diagnostic of the order-exact signed sums of the last xee_ensemble_ee_scalars: per member, how many 32-term chunks of
+ * each integral the parallel algorithm had to add term by term (of (nr-1)*ceil((nz-1)/32)): small on the fast path */
+int xee_ensemble_ee_slow_chunks(xee_ensemble_t *ens, int *sum_Q_slow /* n_members */, int *sum_Qeta_slow /* n_members */);
 int xee_ensemble_records(xee_ensemble_t *ens, xee_case_record_t *out /* n_members */);
 int xee_ensemble_timing(xee_ensemble_t *ens, xee_timing_t *out);
 /* measurement aid: `iters` bare sweep iterations (no checks) of kernel `variant`

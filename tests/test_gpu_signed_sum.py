@@ -73,3 +73,34 @@ def test_signed_sum_with_metric_factors_and_serial_switch():
     xee.set_default_option("exact_sum_serial", 1)          # (conftest resets the defaults after the test)
     assert xee.integrate_weight_B(Q, prof).tobytes() == par.tobytes()
     assert xee.cal_sum_Qeta(Q, eta, prof).tobytes() == H.cal_sum_Qeta(Q, eta, prof).tobytes()
+
+
+def test_ee_integrals_take_the_fast_path_except_under_cancellation():
+    """xee_ensemble_ee_slow_chunks: how many 32-term chunks each EE integral had to add term by term.  sum_Q (terms of one
+    sign) stays on the parallel path for every member; so does sum(Q eta) unless the integral CANCELS: for the bench members
+    whose B has an even number of half-waves in z (m % 5 in {1, 3}) eta is antisymmetric about the level where the heating
+    is symmetric, every column's running sum climbs and falls back through ~20 binades, and a sequential fp32 sum is then
+    serial by nature (each binade crossing changes the rounding unit) -- that is the 8.9 ms k_sx_walk outlier of the round-1
+    profile.  Values are bit-exact against the oracle either way."""
+    import bench
+    nr, nz, M = 512, 256, 10
+    prof = xee.profiles(nr, nz)
+    with xee.Ensemble(nr, nz, M) as e:
+        e.set_profiles(prof)
+        ins = [bench.member_fields(nr, nz, m) for m in range(M)]
+        for m, (A, B, Cc, bc, Q) in enumerate(ins):
+            for n, a in (("A", A), ("B", B), ("C", Cc), ("BC_INIT", bc), ("Q", Q)):
+                e.upload(n, a, first=m)
+        e.forcing_from_B(); e.assemble(xee.BAROTROPIC); e.solve(1500, 1e-8, -1.0, 1.0); e.cal_eta()
+        rec = e.ee_scalars()
+        eta = e.download("ETA")
+        sq, sqe = e.ee_slow_chunks()
+    nchunks = (nr - 1) * -(-(nz - 1) // 32)
+    assert np.all(sq < 0.02 * nchunks), sq
+    for m in range(M):
+        if m % 5 in (0, 2, 4):
+            assert sqe[m] < 0.08 * nchunks, (m, sqe[m], nchunks)
+        hp = H.profiles(nr, nz)
+        assert rec["sum_Q"][m].tobytes() == H.integrate_weight_B(ins[m][4], hp).tobytes()
+        assert rec["sum_Qeta"][m].tobytes() == H.cal_sum_Qeta(ins[m][4], eta[m], hp).tobytes(), m
+    assert max(sqe[m] for m in range(M) if m % 5 in (1, 3)) > 0.1 * nchunks      # the cancelling members are the slow ones

@@ -104,6 +104,7 @@ struct xee_ensemble {
     float* sums = nullptr;
     float* sums_host = nullptr;       // pinned
     std::vector<xee_case_record_t> rec;
+    std::vector<int> sx_slow;     // [2][members]: chunks the last ee_scalars summed term by term (sum_Q, sum_Qeta)
     xee_timing_t timing{};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     SweepOpts opts{};            // sweep options (xee_ensemble_set_option; initialised from the process defaults)
@@ -949,7 +950,7 @@ int ee_sum(xee_ensemble* e, hipStream_t s)
         e->sx_ws = nullptr;
         return fail(XEE_ERR_ALLOC, "hipMalloc signed exact-sum workspace");
     }
-    launch_exact_sum_signed(g, e->terms, 0, g.nx - 1, 0, g.ny - 1, e->sx_ws, e->sums, nullptr, s);
+    launch_exact_sum_signed(g, e->terms, 0, g.nx - 1, 0, g.ny - 1, e->sx_ws, e->sums, e->ex_slow, nullptr, s);
     return XEE_OK;
 }
 }  // namespace
@@ -968,16 +969,28 @@ int xee_ensemble_ee_scalars(xee_ensemble_t* e)
     HIPCHK(hipMemcpyAsync(e->sums_host, e->sums, sizeof(float) * g.members, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     for (int m = 0; m < g.members; ++m) sq[m] = e->sums_host[m];
+    e->sx_slow.assign(2 * (size_t)g.members, 0);
+    if (!e->exact_serial) HIPCHK(hipMemcpy(e->sx_slow.data(), e->ex_slow, sizeof(int) * g.members, hipMemcpyDeviceToHost));
     launch_terms_Qeta(g, e->Q, e->eta, e->terms, e->ra, e->za, e->rcuva, e->rho, s);
     XCHK(ee_sum(e, s));
     HIPCHK(hipMemcpyAsync(e->sums_host, e->sums, sizeof(float) * g.members, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     XCHK(check_launch("ee_scalars"));
+    if (!e->exact_serial) HIPCHK(hipMemcpy(e->sx_slow.data() + g.members, e->ex_slow, sizeof(int) * g.members, hipMemcpyDeviceToHost));
     for (int m = 0; m < g.members; ++m) {
         e->rec[m].sum_Q = sq[m];
         e->rec[m].sum_Qeta = e->sums_host[m];
         e->rec[m].efficiency = e->sums_host[m] / sq[m];      // old-diagnose/diagnose.f90:792-793
     }
+    return XEE_OK;
+}
+
+int xee_ensemble_ee_slow_chunks(xee_ensemble_t* e, int* sum_Q_slow, int* sum_Qeta_slow)
+{
+    if (!e || !sum_Q_slow || !sum_Qeta_slow) return fail(XEE_ERR_INVALID_ARGUMENT, "null argument");
+    if (e->sx_slow.size() != 2 * (size_t)e->g.members) return fail(XEE_ERR_INVALID_ARGUMENT, "xee_ensemble_ee_scalars has not run");
+    memcpy(sum_Q_slow, e->sx_slow.data(), sizeof(int) * e->g.members);
+    memcpy(sum_Qeta_slow, e->sx_slow.data() + e->g.members, sizeof(int) * e->g.members);
     return XEE_OK;
 }
 

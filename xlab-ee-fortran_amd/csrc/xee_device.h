@@ -48,7 +48,8 @@ int    exact_kernel_setup();    // one-time function attributes; returns hipErro
 // sign, bit for bit (the EE integrals); workspace of exact_signed_ws_bytes(g) bytes
 size_t exact_signed_ws_bytes(const Grid& g);
 void launch_exact_sum_signed(const Grid& g, const float* T, int i0, int i1, int j0, int j1, void* workspace,
-                             float* out_sums, const MemberState* st, hipStream_t s);
+                             float* out_sums, int* slow_chunks /* optional, per member: chunks added term by term */,
+                             const MemberState* st, hipStream_t s);
 // out_sums[m] = the reference's sequential fp32 sum of R(i,j)^2 over the interior, bit for bit
 void launch_exact_sumsq(const Grid& g, const float* R, void* workspace, float* out_sums,
                         int* slow_chunks /* optional: chunks summed term by term */,

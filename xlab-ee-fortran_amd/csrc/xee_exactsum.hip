@@ -569,7 +569,7 @@ __global__ __launch_bounds__(256) void k_sx_col_summaries(int ncol, int nseg, co
 // the walk: one wave per member
 __global__ __launch_bounds__(64) void k_sx_walk(Grid g, const float* __restrict__ T, int i0, int j0, int ncol, int nseg, int nrows,
         const SSum* __restrict__ chunk, const SSum* __restrict__ colsum, float* __restrict__ out,
-        const MemberState* __restrict__ st)
+        int* __restrict__ slow_chunks, const MemberState* __restrict__ st)
 {
     const int m = blockIdx.x;
     if (st && !st[m].active) return;
@@ -577,6 +577,7 @@ __global__ __launch_bounds__(64) void k_sx_walk(Grid g, const float* __restrict_
     const float* Tm = T + (size_t)m * g.plane;
     const SSum* cols = colsum + (size_t)m * ncol;
     unsigned bits = 0u;                                       // the sum starts at +0
+    int slow = 0;                                             // chunks added term by term (diagnostic)
 
     auto scan_take = [&](SSum me) -> int {
         const unsigned E = (bits >> 23) & 0xffu;
@@ -653,10 +654,11 @@ __global__ __launch_bounds__(64) void k_sx_walk(Grid g, const float* __restrict_
                 if (r < a.n) sacc = sacc + u2f((unsigned)__builtin_amdgcn_readlane(tb, r));
             bits = f2u(sacc);
             ++seg;
+            ++slow;
         }
         ++col;
     }
-    if (lane == 0) out[m] = u2f(bits);
+    if (lane == 0) { out[m] = u2f(bits); if (slow_chunks) slow_chunks[m] = slow; }
 }
 
 size_t exact_signed_ws_bytes(const Grid& g)
@@ -668,7 +670,7 @@ size_t exact_signed_ws_bytes(const Grid& g)
 }
 
 void launch_exact_sum_signed(const Grid& g, const float* T, int i0, int i1, int j0, int j1, void* workspace,
-                             float* out_sums, const MemberState* st, hipStream_t s)
+                             float* out_sums, int* slow_chunks, const MemberState* st, hipStream_t s)
 {
     const int ncol = i1 - i0, nrows = j1 - j0;
     const int nseg = (nrows + SEG - 1) / SEG;
@@ -686,7 +688,7 @@ void launch_exact_sum_signed(const Grid& g, const float* T, int i0, int i1, int 
     hipLaunchKernelGGL(k_ex_scan_cols, dim3(g.members), dim3(1024), 0, s, ncol, coltot, coloff, st);
     hipLaunchKernelGGL(k_sx_chunk_summaries, gc, bc, 0, s, g, T, i0, j0, ncol, nseg, nrows, sigma, coloff, chunk, st);
     hipLaunchKernelGGL(k_sx_col_summaries, gcol, dim3(256), 0, s, ncol, nseg, chunk, colsum, st);
-    hipLaunchKernelGGL(k_sx_walk, dim3(g.members), dim3(64), 0, s, g, T, i0, j0, ncol, nseg, nrows, chunk, colsum, out_sums, st);
+    hipLaunchKernelGGL(k_sx_walk, dim3(g.members), dim3(64), 0, s, g, T, i0, j0, ncol, nseg, nrows, chunk, colsum, out_sums, slow_chunks, st);
 }
 
 }  // namespace xee

@@ -538,6 +538,13 @@ class Ensemble:
         _chk(lib().xee_ensemble_ee_scalars(self._h))
         return self.records()
 
+    def ee_slow_chunks(self):
+        """-> (sum_Q_slow, sum_Qeta_slow) int arrays: chunks the last ee_scalars added term by term (fast-path diagnostic)."""
+        a, b = np.zeros(self.members, np.int32), np.zeros(self.members, np.int32)
+        lib().xee_ensemble_ee_slow_chunks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _chk(lib().xee_ensemble_ee_slow_chunks(self._h, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)))
+        return a, b
+
     def records(self):
         rec = np.zeros(self.members, RECORD_DTYPE)
         _chk(lib().xee_ensemble_records(self._h, rec.ctypes.data_as(C.c_void_p)))
