@@ -9,7 +9,7 @@ import numpy as np
 import orchelp as H
 
 KINDS = ["tropic", "clinic", "tropic-zero", "clinic-zero", "tropic-explode", "clinic-explode",
-         "tropic-tiny", "tropic-huge", "tropic-negalpha"]
+         "tropic-tiny", "tropic-huge", "tropic-negalpha", "tropic-converged", "clinic-converged", "tropic-converged-negzero"]
 BIG_KINDS = ["tropic-big", "clinic-big"]
 
 
@@ -17,6 +17,14 @@ def build(kind):
     """-> dict(A, B, Cc, bc, forcing, cfg) for xee.diagnose_case / H.diagnose_case."""
     nr, nz = (1024, 512) if "big" in kind else (200, 150)
     variant = "BAROCLINIC" if "clinic" in kind else "BAROTROPIC"
+    if "converged" in kind:               # a small smooth case iterated until whole regions are bitwise stationary: residuals
+        nr, nz = 72, 56                   # that are EXACTLY zero next to a non-zero f (the zero-tolerant validation)
+        A, B, Cc, bc = H.member_inputs(nr, nz, 2, noise=False)
+        if "negzero" in kind:             # ... and a first guess holding -0 in the interior, which forbids that tolerance
+            bc = bc.copy(); bc[10:30, 20:50] = -0.0
+        cfg = dict(mode=("DYNAMIC_EFFICIENCY", "CYLINDRICAL", "DENSITY_NORMAL", variant), domain=(0.0, 1.0, 0.0, 1.0),
+                   r1=1e-12, r2=0.0, max_iter=60000, alpha=1.0)
+        return dict(A=A, B=B, Cc=Cc, bc=bc, forcing=None, cfg=cfg, variant=variant)
     A, B, Cc, bc = H.rich_inputs(nr, nz, seed=3)
     if "tropic" in kind:
         B = np.zeros_like(B)

@@ -38,6 +38,12 @@ def test_every_sweep_body_matches_the_oracle(kind):
     dw = E.digest(want, keys)
     fast = _gpu(c, {})
     assert fast["sweep"]["kernel"] == "k_sweep_q"
+    if "converged" in kind:
+        # the case really has exactly-zero residuals late in the run ...
+        assert float(want["r1"]) < 1e-6, want["r1"]
+        # ... and the optimistic body kept them (no tile left to the exact body at the last check) unless -0 forbids it
+        if "negzero" not in kind:
+            assert fast["timing"]["redo_tiles"] == 0
     assert E.digest(fast, keys) == dw, (kind, "optimistic body", fast["iters"], want["iters"], fast["r1"], want["r1"])
     forced = _gpu(c, {"q_exact_only": 1})
     assert E.digest(forced, keys) == dw, (kind, "exact body of k_sweep_q")

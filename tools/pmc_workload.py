@@ -4,7 +4,7 @@ that calibrate FETCH_SIZE for the two load widths used (k_negate: 16 B/lane; k_c
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d <dir> -- python3 tools/pmc_workload.py <workload>
 
 workload: ensemble | baroclinic | single | highres   (the shapes of bench.py --workload)
-Runs 198 iterations (33 blocked launches, the last but one... plus one residual-writing launch at iteration 100),
+Runs 200 iterations (two blocks of 12 eight-iteration launches plus one residual-writing launch at iterations 100 and 200),
 so every launch is the production kernel on production data; tools/pmc_summarize.py turns the CSVs into
 profiles/<round>/pmc_summary.json and profiles/traffic.json.
 """
@@ -22,7 +22,7 @@ SHAPES = {"ensemble": (1024, 512, 32, 0), "baroclinic": (1024, 512, 32, 1), "sin
 
 def main():
     wl = sys.argv[1] if len(sys.argv) > 1 else "ensemble"
-    iters = int(sys.argv[2]) if len(sys.argv) > 2 else 198
+    iters = int(sys.argv[2]) if len(sys.argv) > 2 else 200
     nr, nz, M, variant = SHAPES[wl]
     xee = xee_pkg.load()
     with xee.Ensemble(nr, nz, M) as e:

@@ -668,10 +668,18 @@ int solve_pipelined(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float 
             HIPCHK(hipEventRecord(e->evB[pk][1], s));
             block_open = false;
             launch_copy_active(g, e->psi[cur], snapbuf[pk], e->st_view, s);   // the iterate this check belongs to
+            // The norm's wide kernels (chunk sums, scans, summaries: ~75 us) stay on the sweep stream -- beside the
+            // sweeps they took compute units from every launch of the next block (+12 % per sweep launch, profiles/r02)
+            // -- and only the serial walk (one wave per member) and the state machine run in the shadow of the sweeps.
+            // Their workspace is shared between checks: check k-1 must have finished with it.
+            if (!e->exact_serial) {
+                if (k >= 1) HIPCHK(hipStreamWaitEvent(s, e->evF[(k - 1) & 1], 0));
+                launch_exact_sumsq_prepare(g, resbuf[pk], e->ex_ws, e->st_view, s);
+            }
             HIPCHK(hipEventRecord(e->evE[pk], s));
             HIPCHK(hipStreamWaitEvent(c, e->evE[pk], 0));
             if (e->exact_serial) launch_seqsum(g, resbuf[pk], 1, g.nx - 1, 1, g.ny - 1, true, e->sums, e->st, c);
-            else launch_exact_sumsq(g, resbuf[pk], e->ex_ws, e->sums, e->ex_slow, e->st, c);
+            else launch_exact_sumsq_walk(g, resbuf[pk], e->ex_ws, e->sums, e->ex_slow, e->st, c);
             cp.cnt = cnt;
             cp.is_last = last ? 1 : 0;
             launch_conv_update(g, e->sums, e->st, cp, c);

@@ -55,6 +55,11 @@ void launch_exact_sumsq(const Grid& g, const float* R, void* workspace, float* o
                         int* slow_chunks /* optional: chunks summed term by term */,
                         const MemberState* st, hipStream_t s);
 
+// ... in two halves, for drivers that keep the wide kernels on the sweep stream and only the serial walk beside it
+void launch_exact_sumsq_prepare(const Grid& g, const float* R, void* workspace, const MemberState* st, hipStream_t s);
+void launch_exact_sumsq_walk(const Grid& g, const float* R, void* workspace, float* out_sums, int* slow_chunks,
+                             const MemberState* st, hipStream_t s);
+
 struct ConvParams {
     float r1, r2;          // after the <=0 -> HUGE substitution (:112-124)
     int converge_time;     // :136-139

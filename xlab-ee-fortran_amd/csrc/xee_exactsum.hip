@@ -408,31 +408,55 @@ int exact_kernel_setup()
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
 }
 
+namespace {
+struct ExactWs { double *sigma, *coltot, *coloff; ExactSum *chunk, *colsum; int ncol, nrows, nseg; };
+ExactWs exact_ws(const Grid& g, void* workspace)
+{
+    ExactWs x;
+    x.ncol = g.nx - 2; x.nrows = g.ny - 2;
+    x.nseg = (x.nrows + SEG - 1) / SEG;
+    const size_t nchunk = (size_t)x.ncol * x.nseg;
+    char* w = static_cast<char*>(workspace);
+    x.sigma = reinterpret_cast<double*>(w);               w += (size_t)g.members * nchunk * sizeof(double);
+    x.coltot = reinterpret_cast<double*>(w);              w += (size_t)g.members * x.ncol * sizeof(double);
+    x.coloff = reinterpret_cast<double*>(w);              w += (size_t)g.members * x.ncol * sizeof(double);
+    x.chunk = reinterpret_cast<ExactSum*>(w);             w += (size_t)g.members * nchunk * sizeof(ExactSum);
+    x.colsum = reinterpret_cast<ExactSum*>(w);
+    return x;
+}
+}  // namespace
+
+// the wide, bandwidth-shaped half: chunk sums, scans, chunk and column summaries (about 75 us for 32 cases of 1024x512)
+void launch_exact_sumsq_prepare(const Grid& g, const float* R, void* workspace, const MemberState* st, hipStream_t s)
+{
+    const ExactWs x = exact_ws(g, workspace);
+    const dim3 gc((x.ncol + 63) / 64, (x.nseg + 3) / 4, g.members), bc(64, 4, 1);
+    const dim3 gcol((x.ncol + 255) / 256, g.members);
+    hipLaunchKernelGGL(k_ex_chunk_sums, gc, bc, 0, s, g, R, x.ncol, x.nseg, x.nrows, x.sigma, st);
+    hipLaunchKernelGGL(k_ex_col_prefix, gcol, dim3(256), 0, s, x.ncol, x.nseg, x.sigma, x.coltot, st);
+    hipLaunchKernelGGL(k_ex_scan_cols, dim3(g.members), dim3(1024), 0, s, x.ncol, x.coltot, x.coloff, st);
+    hipLaunchKernelGGL(k_ex_chunk_summaries, gc, bc, 0, s, g, R, x.ncol, x.nseg, x.nrows, x.sigma, x.coloff, x.chunk, st);
+    hipLaunchKernelGGL(k_ex_col_summaries, gcol, dim3(256), 0, s, x.ncol, x.nseg, x.chunk, x.colsum, st);
+}
+
+// the narrow, serial half: one wave per member walks the summaries (100-160 us, but only `members` waves)
+void launch_exact_sumsq_walk(const Grid& g, const float* R, void* workspace, float* out_sums, int* slow_chunks,
+                             const MemberState* st, hipStream_t s)
+{
+    const ExactWs x = exact_ws(g, workspace);
+    // LDS: all column summaries + the chunk summaries of up to MAXREP columns, when that fits
+    size_t lds = ((size_t)x.ncol + (size_t)MAXREP * x.nseg) * sizeof(ExactSum);
+    int cols_in_lds = 1;
+    if (lds > 128 * 1024) { lds = 0; cols_in_lds = 0; }         // (+ ~15 KiB of static LDS in the walk)
+    hipLaunchKernelGGL(k_ex_walk, dim3(g.members), dim3(64), lds, s, g, R, x.ncol, x.nseg, x.nrows, x.chunk, x.colsum, out_sums,
+                       slow_chunks, st, cols_in_lds);
+}
+
 void launch_exact_sumsq(const Grid& g, const float* R, void* workspace, float* out_sums, int* slow_chunks,
                         const MemberState* st, hipStream_t s)
 {
-    const int ncol = g.nx - 2, nrows = g.ny - 2;
-    const int nseg = (nrows + SEG - 1) / SEG;
-    const size_t nchunk = (size_t)ncol * nseg;
-    char* w = static_cast<char*>(workspace);
-    double* sigma = reinterpret_cast<double*>(w);               w += (size_t)g.members * nchunk * sizeof(double);
-    double* coltot = reinterpret_cast<double*>(w);              w += (size_t)g.members * ncol * sizeof(double);
-    double* coloff = reinterpret_cast<double*>(w);              w += (size_t)g.members * ncol * sizeof(double);
-    ExactSum* chunk = reinterpret_cast<ExactSum*>(w);           w += (size_t)g.members * nchunk * sizeof(ExactSum);
-    ExactSum* colsum = reinterpret_cast<ExactSum*>(w);
-    const dim3 gc((ncol + 63) / 64, (nseg + 3) / 4, g.members), bc(64, 4, 1);
-    const dim3 gcol((ncol + 255) / 256, g.members);
-    hipLaunchKernelGGL(k_ex_chunk_sums, gc, bc, 0, s, g, R, ncol, nseg, nrows, sigma, st);
-    hipLaunchKernelGGL(k_ex_col_prefix, gcol, dim3(256), 0, s, ncol, nseg, sigma, coltot, st);
-    hipLaunchKernelGGL(k_ex_scan_cols, dim3(g.members), dim3(1024), 0, s, ncol, coltot, coloff, st);
-    hipLaunchKernelGGL(k_ex_chunk_summaries, gc, bc, 0, s, g, R, ncol, nseg, nrows, sigma, coloff, chunk, st);
-    hipLaunchKernelGGL(k_ex_col_summaries, gcol, dim3(256), 0, s, ncol, nseg, chunk, colsum, st);
-    // LDS: all column summaries + the chunk summaries of up to MAXREP columns, when that fits
-    size_t lds = ((size_t)ncol + (size_t)MAXREP * nseg) * sizeof(ExactSum);
-    int cols_in_lds = 1;
-    if (lds > 128 * 1024) { lds = 0; cols_in_lds = 0; }         // (+ ~15 KiB of static LDS in the walk)
-    hipLaunchKernelGGL(k_ex_walk, dim3(g.members), dim3(64), lds, s, g, R, ncol, nseg, nrows, chunk, colsum, out_sums,
-                       slow_chunks, st, cols_in_lds);
+    launch_exact_sumsq_prepare(g, R, workspace, st, s);
+    launch_exact_sumsq_walk(g, R, workspace, out_sums, slow_chunks, st, s);
 }
 
 // =============================================================================================

@@ -799,15 +799,21 @@ __global__ __launch_bounds__(256) void k_uniform_check(Grid g, const float* __re
 {
     const int i = blockIdx.x * 64 + threadIdx.x;
     const int j = blockIdx.y * 4 + threadIdx.y;
-    if (i < 1 || i > g.nx - 2 || j < 1 || j > g.ny - 2) return;
-    const size_t o = (size_t)blockIdx.z * g.plane + (size_t)j * g.pitch + i;
+    const bool in = i >= 1 && i <= g.nx - 2 && j >= 1 && j <= g.ny - 2;
+    const size_t o = (size_t)blockIdx.z * g.plane + (size_t)(in ? j : 1) * g.pitch + (in ? i : 1);
     const size_t ref = (size_t)g.pitch + 1;               // member 0, point (1,1)
     const size_t ks = (size_t)g.members * g.plane;
-    unsigned bad = 0;
+    unsigned wave_bad = 0;                                // (a wave = one row of the block: threadIdx.x is the lane)
 #pragma unroll
-    for (int k = 0; k < 9; ++k)
-        if (__builtin_bit_cast(unsigned, coe[k * ks + o]) != __builtin_bit_cast(unsigned, coe[k * ks + ref])) bad |= 1u << k;
-    if (bad) atomicOr(differs, bad);
+    for (int k = 0; k < 9; ++k) {
+        const bool d = in && __builtin_bit_cast(unsigned, coe[k * ks + o]) != __builtin_bit_cast(unsigned, coe[k * ks + ref]);
+        if (__builtin_amdgcn_ballot_w64(d) != 0) wave_bad |= 1u << k;
+    }
+    // one atomic per wave, and none once the word already holds these bits (every thread hitting the same word cost 3 ms)
+    if (threadIdx.x == 0 && wave_bad) {
+        const unsigned cur = __hip_atomic_load(differs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((cur | wave_bad) != cur) atomicOr(differs, wave_bad);
+    }
 }
 
 // do two sets of nine coefficient planes hold the same bits over the interior of every member?

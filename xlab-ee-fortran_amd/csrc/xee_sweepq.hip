@@ -18,6 +18,8 @@
 //     dynamic  max(2^-100, dmax*2^-120) <= |alpha*R| <= min(2^100, dmin*2^94) at every interior point
 //              and every one of the T steps (running max/min of |alpha*R|: one v_max3/v_min3 per two points),
 //              and every value of the tile finite at the end (non-finite values are sticky under the update)
+//              (round 2: a residual that is EXACTLY zero is admitted where it provably is harmless -- see "Zero
+//              residuals" below; converged regions produce them by the thousand late in a long run)
 // which keeps the exponent difference below the 96 where div_scale starts to rescale and quotient,
 // reciprocal and remainders normal and exactly representable (tests/test_gpu_quotient.py checks the
 // identity over 10^9 operand pairs drawn over the whole admitted range).  A tile that fails any of it (a
@@ -33,6 +35,17 @@
 //  * no select for the points that never update (rim, outside the domain): their weights are set to 0, f
 //    to -1 and y1 to the zero whose sign makes q2 = -0, so `psi + q2` returns psi bit for bit and their
 //    "residual" alpha*1 stays inside the dynamic bound.
+//
+// Zero residuals.  A point whose residual is exactly zero has a = alpha*R = +-0 and both forms of the quotient give a
+// zero; psi + (+-0) is psi for either sign unless psi is -0.  An update cannot create a -0 (x + y is -0 only for
+// -0 + -0), so a lane whose loaded interior psi hold no -0 may take zeros -- PROVIDED nothing in (0, a_lo) can hide
+// behind them, which the running minimum of |a| can no longer tell.  It cannot where f is not tiny: R = fl(s - f) of two
+// floats is either zero or at least |f| * 2^-25 (opposite signs or a factor two apart: more than |f|/2; within a factor
+// two: an exact, non-zero multiple of the smaller one's ulp), so with fmin = min |f| over the lane's interior points and
+// |alpha| * fmin * 2^-26 >= a_lo every non-zero |a| is above the lower bound by construction and the minimum need not be
+// looked at.  (The five-point star's argument above needs a = 0 to be rejected only when f = 0 as well: then fmin = 0
+// and the lane keeps the strict rule.)  Without this, 2-3 % of the tiles of the bench's ensemble fell to the exact body
+// from ~5,000 iterations on, and the stragglers stretched every launch by 12 % (profiles/r02).
 //
 // Round 2: the optimistic body is written in PACKED fp32 (v_pk_mul/add/fma_f32: two points per instruction, each
 // half rounded separately -- the same bits as two scalar operations).  A lane's R rows are paired (k, k + R/2), so the
@@ -149,6 +162,8 @@ __device__ __forceinline__ bool fast_tile(const Grid& g, const TileGeom& tg, flo
 
     f2 c[NC][H2], ff[H2], y1[H2], p[H2];
     float dmin = 0x1p120f, dmax = 0x1p-120f;            // extremes of |coe5| over this lane's interior points
+    float fmin = __builtin_inff();                      // min |f| over them, and whether one of their psi is -0
+    bool neg_zero_psi = false;
     {
         // Every load of the tile is issued before the first value is used, unconditionally and from a
         // clamped (always valid) address; what lies outside the domain is replaced afterwards.  Row offsets are
@@ -225,6 +240,8 @@ __device__ __forceinline__ bool fast_tile(const Grid& g, const TileGeom& tg, flo
             // (a NaN d passes through fmin/fmax unnoticed, but then y1 and every iterate of the point are NaN)
             dmin = interior ? __builtin_fminf(dmin, __builtin_fabsf(d)) : dmin;
             dmax = interior ? __builtin_fmaxf(dmax, __builtin_fabsf(d)) : dmax;
+            fmin = interior ? __builtin_fminf(fmin, __builtin_fabsf(rf[r])) : fmin;
+            neg_zero_psi = neg_zero_psi || (interior && __builtin_bit_cast(unsigned, rp[r]) == 0x80000000u);
             cq_m = Cp;
             by_m = BYp;
         }
@@ -339,7 +356,9 @@ __device__ __forceinline__ bool fast_tile(const Grid& g, const TileGeom& tg, flo
         bool ok = dmin >= 0x1p-120f && dmax <= 0x1p120f;
         const float a_lo = __builtin_fmaxf(0x1p-100f, dmax * 0x1p-120f);
         const float a_hi = __builtin_fminf(0x1p100f, dmin * 0x1p94f);
-        ok = ok && amin >= a_lo && amax <= a_hi;
+        // (see "Zero residuals" in the header: where every non-zero |a| is above a_lo by construction, zeros may pass)
+        const bool zero_ok = !neg_zero_psi && __builtin_fabsf(alpha) * fmin * 0x1p-26f >= a_lo;
+        ok = ok && (zero_ok || amin >= a_lo) && amax <= a_hi;
 #pragma unroll
         for (int k = 0; k < H2; ++k) {
             const f2 v = in_q ? q[k] : p[k];
