@@ -221,20 +221,27 @@ int detect_uniform_planes(xee_ensemble* e)
 
 // T iterations of the blocked sweep: from the four generating planes when assemble built them
 // (fewer bytes), else from the nine coefficient planes (any coefficients, e.g. a Tier-1 caller's)
-void launch_blocked(xee_ensemble* e, const float* psi_in, float* psi_out, float* res, float alpha, int T,
-                    const MemberState* st = nullptr /* default: e->st */)
+// returns true when the kernel itself also wrote the new iterate's interior into `snap` (k_sweep_q's residual-writing
+// launch can; the other kernels leave the snapshot to a copy)
+bool launch_blocked(xee_ensemble* e, const float* psi_in, float* psi_out, float* res, float alpha, int T,
+                    const MemberState* st = nullptr /* default: e->st */, float* snap = nullptr)
 {
     const int k = e->opts.kernel;
     if (!st) st = e->st;
     if (e->have_base && k != 1) {
         if (k == 2) launch_sweep_tb4(e->g, psi_in, psi_out, e->base, e->f, res, st, alpha, T, e->base_baro, e->opts, &e->last_sweep, e->stream);
         else {
-            if (!e->redo && hipMalloc(reinterpret_cast<void**>(&e->redo), sizeof(int) * sweep_q_redo_ints(e->g)) != hipSuccess) { e->redo = nullptr; return; }   // (the launch check after the block reports it)
-            launch_sweep_q(e->g, psi_in, psi_out, e->base, e->f, res, st, alpha, T, e->base_baro, e->opts, e->redo, &e->last_sweep, e->stream);
+            if (!e->redo) {
+                if (hipMalloc(reinterpret_cast<void**>(&e->redo), sizeof(int) * sweep_q_redo_ints(e->g)) != hipSuccess) { e->redo = nullptr; return false; }   // (the launch check after the block reports it)
+                (void)hipMemsetAsync(e->redo, 0, sizeof(int) * sweep_q_redo_ints(e->g), e->stream);
+            }
+            launch_sweep_q(e->g, psi_in, psi_out, e->base, e->f, res, res ? snap : nullptr, st, alpha, T, e->base_baro, e->opts, e->redo, &e->last_sweep, e->stream);
+            return res && snap;
         }
     }
     else
         launch_sweep_tb(e->g, psi_in, psi_out, e->coe, e->f, res, st, alpha, T, e->uv, e->opts, &e->last_sweep, e->stream);
+    return false;
 }
 
 int check_launch(const char* what)
@@ -622,6 +629,9 @@ int solve_pipelined(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float 
     hipStream_t c = e->cstream;
     float* resbuf[2] = {e->res, e->res2};
     float* snapbuf[2] = {e->snap, e->snap + (size_t)g.members * g.plane};
+    // both snapshot slots start as full copies of the first guess: the rim never changes, and a residual-writing sweep
+    // launch that fills the snapshot itself only stores interior points
+    launch_copy2(g, e->psi[e->cur], snapbuf[0], snapbuf[1], s);
 
     int cur = e->cur;
     std::vector<int> stop_slot(g.members, -1);    // snapshot slot holding a stopped member's result
@@ -657,29 +667,35 @@ int solve_pipelined(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float 
         const int pk = k & 1;
         if (!block_open) { HIPCHK(hipEventRecord(e->evB[pk][0], s)); block_open = true; }
         if (check && k >= 2) { HIPCHK(hipStreamWaitEvent(s, e->evF[pk], 0)); XCHK(refresh_view()); }   // res/snap slot pk is free again
+        bool snapped = false;
         if (n == 1)
             launch_sweep(g, e->psi[cur], e->psi[cur ^ 1], e->coe, e->f, check ? resbuf[pk] : nullptr, e->st_view, alpha, s);
         else
-            launch_blocked(e, e->psi[cur], e->psi[cur ^ 1], check ? resbuf[pk] : nullptr, alpha, n, e->st_view);
+            snapped = launch_blocked(e, e->psi[cur], e->psi[cur ^ 1], check ? resbuf[pk] : nullptr, alpha, n, e->st_view,
+                                     check ? snapbuf[pk] : nullptr);
         cur ^= 1;
         e->timing.sweep_launches += 1;
         e->timing.iterations += n;
         if (check) {
             HIPCHK(hipEventRecord(e->evB[pk][1], s));
             block_open = false;
-            launch_copy_active(g, e->psi[cur], snapbuf[pk], e->st_view, s);   // the iterate this check belongs to
+            if (!snapped) launch_copy_active(g, e->psi[cur], snapbuf[pk], e->st_view, s);   // the iterate this check belongs to
             // The norm's wide kernels (chunk sums, scans, summaries: ~75 us) stay on the sweep stream -- beside the
             // sweeps they took compute units from every launch of the next block (+12 % per sweep launch, profiles/r02)
             // -- and only the serial walk (one wave per member) and the state machine run in the shadow of the sweeps.
             // Their workspace is shared between checks: check k-1 must have finished with it.
-            if (!e->exact_serial) {
+            // (a small batch leaves the machine half empty anyway: there the whole norm stays beside the sweeps, whose
+            // block of 100 iterations is shorter than the wide kernels would add)
+            const bool wide_on_sweep_stream = !e->exact_serial && (size_t)g.members * g.nx * g.ny >= ((size_t)4 << 20);
+            if (wide_on_sweep_stream) {
                 if (k >= 1) HIPCHK(hipStreamWaitEvent(s, e->evF[(k - 1) & 1], 0));
                 launch_exact_sumsq_prepare(g, resbuf[pk], e->ex_ws, e->st_view, s);
             }
             HIPCHK(hipEventRecord(e->evE[pk], s));
             HIPCHK(hipStreamWaitEvent(c, e->evE[pk], 0));
             if (e->exact_serial) launch_seqsum(g, resbuf[pk], 1, g.nx - 1, 1, g.ny - 1, true, e->sums, e->st, c);
-            else launch_exact_sumsq_walk(g, resbuf[pk], e->ex_ws, e->sums, e->ex_slow, e->st, c);
+            else if (wide_on_sweep_stream) launch_exact_sumsq_walk(g, resbuf[pk], e->ex_ws, e->sums, e->ex_slow, e->st, c);
+            else launch_exact_sumsq(g, resbuf[pk], e->ex_ws, e->sums, e->ex_slow, e->st, c);
             cp.cnt = cnt;
             cp.is_last = last ? 1 : 0;
             launch_conv_update(g, e->sums, e->st, cp, c);
@@ -722,7 +738,7 @@ int solve_pipelined(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float 
         HIPCHK(hipMemcpyAsync(e->psi[cur] + (size_t)m * g.plane, snapbuf[stop_slot[m]] + (size_t)m * g.plane,
                               sizeof(float) * g.plane, hipMemcpyDeviceToDevice, s));
     }
-    if (e->redo) { int n = 0; HIPCHK(hipMemcpyAsync(&n, e->redo, sizeof(int), hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s)); e->timing.redo_tiles = n; }
+    if (e->redo) { int n = 0; HIPCHK(hipMemcpyAsync(&n, e->redo + sweep_q_redo_ints(g) - 1, sizeof(int), hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s)); e->timing.redo_tiles = n; }
     // XEE_F_RESIDUAL = the residual plane of each member's LAST check (include/xee.h): checks alternated between two
     // planes; a stopped member's is the one of its stopping check, everyone else's the one of the last check enqueued
     for (int m = 0; m < g.members && k >= 1; ++m) {

@@ -150,7 +150,8 @@ __device__ __forceinline__ void stamp(const TileGeom& tg, int slot)
 template <int NW, int R, bool WRITE_R, bool BARO, bool ALPHA1, bool INNER, bool STAMP>
 __device__ __forceinline__ bool fast_tile(const Grid& g, const TileGeom& tg, float (*edge)[2][NW][64], int* vote,
         const float* __restrict__ psi_in, float* __restrict__ psi_out, const float* __restrict__ base,
-        const float* __restrict__ f, float* __restrict__ res, float alpha, int T, const MemberState* __restrict__ member)
+        const float* __restrict__ f, float* __restrict__ res, float* __restrict__ snap, float alpha, int T,
+        const MemberState* __restrict__ member)
 {
     static_assert(R % 2 == 0 && R >= 4, "rows are processed in pairs (k, k + R/2)");
     constexpr int H = NW * R;
@@ -387,7 +388,11 @@ __device__ __forceinline__ bool fast_tile(const Grid& g, const TileGeom& tg, flo
                 const int o = gy * g.pitch * 4;
                 const f2 v = in_q ? q[k] : p[k];
                 bstore(outr, sx, o, r < H2 ? v.x : v.y);
-                if constexpr (WRITE_R) bstore(plane_rsrc(res + mo, g), sx, o, r < H2 ? rl[k].x : rl[k].y);
+                if constexpr (WRITE_R) {
+                    bstore(plane_rsrc(res + mo, g), sx, o, r < H2 ? rl[k].x : rl[k].y);
+                    // the pipelined driver's snapshot of the iterate this check belongs to (xee_api.hip), when asked for
+                    if (snap) bstore(plane_rsrc(snap + mo, g), sx, o, r < H2 ? v.x : v.y);
+                }
             }
         }
     }
@@ -400,7 +405,8 @@ __device__ __forceinline__ bool fast_tile(const Grid& g, const TileGeom& tg, flo
 template <int NW, int R, bool WRITE_R, bool BARO>
 __device__ __forceinline__ void exact_tile(const Grid& g, const TileGeom& tg, float (*edge)[2][NW][64],
         const float* __restrict__ psi_in, float* __restrict__ psi_out, const float* __restrict__ base,
-        const float* __restrict__ f, float* __restrict__ res, float alpha, int T, const MemberState* __restrict__ member)
+        const float* __restrict__ f, float* __restrict__ res, float* __restrict__ snap, float alpha, int T,
+        const MemberState* __restrict__ member)
 {
     constexpr int H = NW * R;
     const int lane = tg.lane, w = tg.w, gx = tg.gx, gy0 = tg.gy0;
@@ -508,7 +514,10 @@ __device__ __forceinline__ void exact_tile(const Grid& g, const TileGeom& tg, fl
         const int gy = gy0 + r;
         const bool vy = (ly >= T || tg.y0 <= 0) && (ly < H - T || tg.y0 + H - 1 >= g.ny - 1);
         const bool interior = tg.col_int && gy >= 1 && gy <= g.ny - 2;
-        if (tg.vx && vy && interior) psi_out[mo + (size_t)gy * g.pitch + gx] = in_q ? q[r] : p[r];
+        if (tg.vx && vy && interior) {
+            psi_out[mo + (size_t)gy * g.pitch + gx] = in_q ? q[r] : p[r];
+            if (WRITE_R && snap) snap[mo + (size_t)gy * g.pitch + gx] = in_q ? q[r] : p[r];
+        }
     }
 }
 
@@ -544,7 +553,7 @@ __device__ __forceinline__ TileGeom make_geom(const Grid& g, int T, int bx, int 
 template <int NW, int R, bool WRITE_R, bool BARO, bool ALPHA1, bool STAMP = false>
 __global__ __launch_bounds__(NW * 64, (BARO || NW * R < 64) ? 4 : 1) void k_sweep_q(Grid g, const float* __restrict__ psi_in,
         float* __restrict__ psi_out, const float* __restrict__ base, const float* __restrict__ f,
-        float* __restrict__ res, const MemberState* __restrict__ st, float alpha, int T, int exact_only,
+        float* __restrict__ res, float* __restrict__ snap, const MemberState* __restrict__ st, float alpha, int T, int exact_only,
         int* __restrict__ redo, unsigned long long* __restrict__ stamps)
 {
     __shared__ float edge[2][2][NW][64];
@@ -561,8 +570,8 @@ __global__ __launch_bounds__(NW * 64, (BARO || NW * R < 64) ? 4 : 1) void k_swee
     }
     if (!exact_only) {
         const bool done = tg.inner
-            ? fast_tile<NW, R, WRITE_R, BARO, ALPHA1, true, STAMP>(g, tg, edge, vote, psi_in, psi_out, base, f, res, alpha, T, member)
-            : fast_tile<NW, R, WRITE_R, BARO, ALPHA1, false, STAMP>(g, tg, edge, vote, psi_in, psi_out, base, f, res, alpha, T, member);
+            ? fast_tile<NW, R, WRITE_R, BARO, ALPHA1, true, STAMP>(g, tg, edge, vote, psi_in, psi_out, base, f, res, snap, alpha, T, member)
+            : fast_tile<NW, R, WRITE_R, BARO, ALPHA1, false, STAMP>(g, tg, edge, vote, psi_in, psi_out, base, f, res, snap, alpha, T, member);
         if (done) {
             stamp<STAMP>(tg, 6);
             return;
@@ -574,7 +583,7 @@ __global__ __launch_bounds__(NW * 64, (BARO || NW * R < 64) ? 4 : 1) void k_swee
             redo[1 + slot] = (int)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
         }
     } else {
-        exact_tile<NW, R, WRITE_R, BARO>(g, tg, edge, psi_in, psi_out, base, f, res, alpha, T, member);
+        exact_tile<NW, R, WRITE_R, BARO>(g, tg, edge, psi_in, psi_out, base, f, res, snap, alpha, T, member);
     }
     stamp<STAMP>(tg, 6);
 }
@@ -582,8 +591,8 @@ __global__ __launch_bounds__(NW * 64, (BARO || NW * R < 64) ? 4 : 1) void k_swee
 // the tiles a residual-writing launch left to the exact body (usually none: the grid then finds count == 0 and ends)
 template <int NW, int R, bool BARO>
 __global__ __launch_bounds__(NW * 64) void k_sweep_q_redo(Grid g, const float* __restrict__ psi_in, float* __restrict__ psi_out,
-        const float* __restrict__ base, const float* __restrict__ f, float* __restrict__ res,
-        const MemberState* __restrict__ st, float alpha, int T, const int* __restrict__ redo, int ntx, int nty)
+        const float* __restrict__ base, const float* __restrict__ f, float* __restrict__ res, float* __restrict__ snap,
+        const MemberState* __restrict__ st, float alpha, int T, int* __restrict__ redo, int ntx, int nty, int done_slot)
 {
     __shared__ float edge[2][2][NW][64];
     const int count = redo[0];
@@ -591,8 +600,15 @@ __global__ __launch_bounds__(NW * 64) void k_sweep_q_redo(Grid g, const float* _
         const int id = redo[1 + i];
         const int bx = id % ntx, by = (id / ntx) % nty, m = id / (ntx * nty);
         const TileGeom tg = make_geom<NW, R>(g, T, bx, by, m);
-        exact_tile<NW, R, true, BARO>(g, tg, edge, psi_in, psi_out, base, f, res, alpha, T, st ? st + m : nullptr);
+        exact_tile<NW, R, true, BARO>(g, tg, edge, psi_in, psi_out, base, f, res, snap, alpha, T, st ? st + m : nullptr);
         __syncthreads();                                  // the edge rows are reused by the next tile
+    }
+    // the list is consumed: the last workgroup to get here empties it for the next residual-writing launch
+    // (redo[done_slot] counts arrivals, redo[done_slot + 1] keeps the count for xee_timing_t.redo_tiles; every workgroup
+    // has read redo[0] before it arrives)
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(redo + done_slot, 1) == (int)gridDim.x - 1) { redo[done_slot + 1] = count; redo[0] = 0; redo[done_slot] = 0; __threadfence(); }
     }
 }
 
@@ -654,17 +670,16 @@ __global__ __launch_bounds__(256) void k_quotient_check(unsigned long long seed,
 
 template <int NW, int R, bool BARO>
 static void launch_q_cfg(const Grid& g, const float* psi_in, float* psi_out, const float* base, const float* f,
-                         float* res, const MemberState* st, float alpha, int T, int exact_only, int* redo, hipStream_t s)
+                         float* res, float* snap, const MemberState* st, float alpha, int T, int exact_only, int* redo, hipStream_t s)
 {
     constexpr int H = NW * R;
     dim3 grid((g.nx - 1 + (64 - 2 * T) - 1) / (64 - 2 * T), (g.ny - 1 + (H - 2 * T) - 1) / (H - 2 * T), g.members);
     const bool a1 = alpha == 1.0f;     // the protocol's damping: 1.0f * x is x, the multiply is not issued
-#define Q_LAUNCH(WR, A1) hipLaunchKernelGGL((k_sweep_q<NW, R, WR, BARO, A1>), grid, dim3(NW * 64), 0, s, g, psi_in, psi_out, base, f, res, st, alpha, T, exact_only, redo, (unsigned long long*)nullptr)
-    if (res) {
-        (void)hipMemsetAsync(redo, 0, sizeof(int), s);
+#define Q_LAUNCH(WR, A1) hipLaunchKernelGGL((k_sweep_q<NW, R, WR, BARO, A1>), grid, dim3(NW * 64), 0, s, g, psi_in, psi_out, base, f, res, snap, st, alpha, T, exact_only, redo, (unsigned long long*)nullptr)
+    if (res) {                         // (redo[0] is zero here: zeroed at allocation, and by every k_sweep_q_redo when it ends)
         if (a1) Q_LAUNCH(true, true); else Q_LAUNCH(true, false);
-        hipLaunchKernelGGL((k_sweep_q_redo<NW, R, BARO>), dim3(exact_only ? 1024 : 64), dim3(NW * 64), 0, s, g, psi_in, psi_out, base, f, res, st,
-                           alpha, T, (const int*)redo, (int)grid.x, (int)grid.y);
+        hipLaunchKernelGGL((k_sweep_q_redo<NW, R, BARO>), dim3(exact_only ? 1024 : 64), dim3(NW * 64), 0, s, g, psi_in, psi_out, base, f, res, snap, st,
+                           alpha, T, redo, (int)grid.x, (int)grid.y, (int)sweep_q_redo_ints(g) - 2);
     }
     else { if (a1) Q_LAUNCH(false, true); else Q_LAUNCH(false, false); }
 #undef Q_LAUNCH
@@ -672,12 +687,13 @@ static void launch_q_cfg(const Grid& g, const float* psi_in, float* psi_out, con
 
 size_t sweep_q_redo_ints(const Grid& g)
 {
-    // one slot per tile of the densest tiling launch_sweep_q admits (tile steps >= 16 columns, >= 8 rows), plus the count
-    return (size_t)g.members * ((g.nx + 15) / 16) * ((g.ny + 7) / 8) + 1;
+    // the count, one slot per tile of the densest tiling launch_sweep_q admits (tile steps >= 16 columns, >= 8 rows), the
+    // redo kernel's arrival counter and the last launch's count (diagnostic); the caller zeroes the buffer once
+    return (size_t)g.members * ((g.nx + 15) / 16) * ((g.ny + 7) / 8) + 3;
 }
 
 void launch_sweep_q(const Grid& g, const float* psi_in, float* psi_out, const float* base, const float* f,
-                    float* res, const MemberState* st, float alpha, int T, bool barotropic, const SweepOpts& o,
+                    float* res, float* snap, const MemberState* st, float alpha, int T, bool barotropic, const SweepOpts& o,
                     int* redo, SweepDesc* desc, hipStream_t s)
 {
     const int exact_only = o.q_exact_only ? 1 : 0;
@@ -687,8 +703,8 @@ void launch_sweep_q(const Grid& g, const float* psi_in, float* psi_out, const fl
     if ((cfg / 100) * (cfg % 100) - 2 * T < 8) cfg = 808;           // the tile must keep a useful core
     if (desc) { desc->name = barotropic ? "k_sweep_q<star>" : "k_sweep_q<nine>"; desc->T = T; desc->tile_w = 64; desc->tile_h = (cfg / 100) * (cfg % 100); }
 #define Q_CASE(NW, R) case NW * 100 + R: \
-        if (barotropic) launch_q_cfg<NW, R, true>(g, psi_in, psi_out, base, f, res, st, alpha, T, exact_only, redo, s); \
-        else launch_q_cfg<NW, R, false>(g, psi_in, psi_out, base, f, res, st, alpha, T, exact_only, redo, s); \
+        if (barotropic) launch_q_cfg<NW, R, true>(g, psi_in, psi_out, base, f, res, snap, st, alpha, T, exact_only, redo, s); \
+        else launch_q_cfg<NW, R, false>(g, psi_in, psi_out, base, f, res, snap, st, alpha, T, exact_only, redo, s); \
         break;
     switch (cfg) {
         Q_CASE(8, 8)
