@@ -26,9 +26,9 @@ def test_bench_prints_one_json_line_with_required_keys():
     assert d["unit"] == "cases/s" and d["n_gpus"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
     r = d["roofline"]
-    # the blocked sweep is VALU-issue bound: priced in flop/s against the unfused fp32 issue peak; the byte view
+    # the blocked sweep is VALU-issue bound: priced in flop/s against the unfused (packed) fp32 issue peak; the byte view
     # (algorithmic, compulsory and measured-traffic rates against the 8 TB/s HBM peak) sits beside it
-    assert r["bound"] == "valu" and r["unit"] == "TFLOP/s" and r["peak"] == 39.3 and r["peak_spec"] == 157.3
+    assert r["bound"] == "valu" and r["unit"] == "TFLOP/s" and r["peak"] == 78.6 and r["peak_spec"] == 157.3
     assert 0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and "traffic" in r
     h = r["hbm"]
     assert h["peak_GBps"] == 8000.0 and h["algorithmic_bytes_per_point_iter"] == 20.0 and h["compulsory_GBps"] > 0
