@@ -235,8 +235,7 @@ bool launch_blocked(xee_ensemble* e, const float* psi_in, float* psi_out, float*
                 if (hipMalloc(reinterpret_cast<void**>(&e->redo), sizeof(int) * sweep_q_redo_ints(e->g)) != hipSuccess) { e->redo = nullptr; return false; }   // (the launch check after the block reports it)
                 (void)hipMemsetAsync(e->redo, 0, sizeof(int) * sweep_q_redo_ints(e->g), e->stream);
             }
-            launch_sweep_q(e->g, psi_in, psi_out, e->base, e->f, res, res ? snap : nullptr, st, alpha, T, e->base_baro, e->opts, e->redo, &e->last_sweep, e->stream);
-            return res && snap;
+            return launch_sweep_q(e->g, psi_in, psi_out, e->base, e->f, res, res ? snap : nullptr, st, alpha, T, e->base_baro, e->opts, e->redo, &e->last_sweep, e->stream);
         }
     }
     else

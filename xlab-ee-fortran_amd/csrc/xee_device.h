@@ -117,7 +117,8 @@ void launch_sweep_tb4(const Grid& g, const float* psi_in, float* psi_out, const 
                       SweepDesc* desc, hipStream_t s);
 // the same, with the loop-invariant half of the update's division hoisted and a validated optimistic body
 // per tile (xee_sweepq.hip); bit-identical to launch_sweep_tb4
-void launch_sweep_q(const Grid& g, const float* psi_in, float* psi_out, const float* base, const float* f,
+// (returns whether a residual-writing launch also wrote `snap`)
+bool launch_sweep_q(const Grid& g, const float* psi_in, float* psi_out, const float* base, const float* f,
                     float* res, float* snap /* residual-writing launches: a second copy of the new iterate's valid points, or nullptr */,
                     const MemberState* st, float alpha, int T, bool barotropic, const SweepOpts& o,
                     int* redo /* device, sweep_q_redo_ints(g) ints: tiles a residual-writing launch leaves to the exact body */,

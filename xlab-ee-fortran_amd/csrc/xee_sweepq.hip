@@ -692,10 +692,16 @@ size_t sweep_q_redo_ints(const Grid& g)
     return (size_t)g.members * ((g.nx + 15) / 16) * ((g.ny + 7) / 8) + 3;
 }
 
-void launch_sweep_q(const Grid& g, const float* psi_in, float* psi_out, const float* base, const float* f,
+bool launch_sweep_q(const Grid& g, const float* psi_in, float* psi_out, const float* base, const float* f,
                     float* res, float* snap, const MemberState* st, float alpha, int T, bool barotropic, const SweepOpts& o,
                     int* redo, SweepDesc* desc, hipStream_t s)
 {
+    // the buffer descriptors address one member's plane with 32-bit byte offsets: a plane of 2 GiB or more (a 23,000 x 23,000
+    // grid) goes to the kernel with 64-bit addressing
+    if (g.plane * sizeof(float) >= ((size_t)1 << 31)) {
+        launch_sweep_tb4(g, psi_in, psi_out, base, f, res, st, alpha, T, barotropic, o, desc, s);
+        return false;
+    }
     const int exact_only = o.q_exact_only ? 1 : 0;
     // (the nine-weight body needs too many registers at eight rows per lane for two workgroups per CU; at six it fits)
     int cfg = o.tile;
@@ -712,6 +718,7 @@ void launch_sweep_q(const Grid& g, const float* psi_in, float* psi_out, const fl
         Q_CASE(8, 4)
     }
 #undef Q_CASE
+    return res && snap;            // the residual-writing launch also filled the snapshot
 }
 
 void launch_quotient_check(unsigned long long seed, int blocks, int per_thread, int d_exp_lo, int d_exp_hi,
