@@ -364,7 +364,9 @@ def main():
         try:
             gh = json.loads((ROOT / "tests" / "golden" / "golden_hashes.json").read_text())
             key = f"bench_m0{'_baroclinic' if operator == 'BAROCLINIC' else ''}_{args.max_iter}"
-            if (nr, nz) == (1024, 512) and key in gh:
+            if (nr, nz) != (1024, 512):
+                key = f"bench_m0_{nr}x{nz}_{args.max_iter}" if operator == "BAROTROPIC" else ""
+            if key in gh and gh[key]["shape"] == [nr, nz]:
                 g = gh[key]["md5"]
                 tag = "BAROCLINIC" if operator == "BAROCLINIC" else "BAROTROPIC"
                 chk["golden"] = f"tests/golden/golden_hashes.json:{key} (the reference program's own output)"

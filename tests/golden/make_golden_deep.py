@@ -41,19 +41,22 @@ def cases():
         c[f"member{m}_1024x512_600"] = ("member", m, BT, 600)
     for m in (1, 6):
         c[f"member{m}_1024x512_600_baroclinic"] = ("member", m, BC, 600)
+    # the highres workload of bench.py (configs[3]): member 0 at 4096x2048, 2,000 iterations (~25 min of the reference)
+    c["bench_m0_4096x2048_2000"] = ("member4096", 0, BT, 2000)
     return c
 
 
 def one(args):
     name, (kind, m, mode, iters) = args
-    A, B, Cc, bc = H.test1_inputs(1024, 512) if kind == "test1" else H.member_inputs(1024, 512, m)
+    nr, nz = (4096, 2048) if kind == "member4096" else (1024, 512)
+    A, B, Cc, bc = H.test1_inputs(nr, nz) if kind == "test1" else H.member_inputs(nr, nz, m)
     cfg = dict(mode=mode, r1=1e-8, r2=-1.0, max_iter=iters, alpha=1.0)
     with tempfile.TemporaryDirectory() as td:
         stdout, outs = H.run_ref_diagnose(td, A, B, Cc, bc, None, **cfg)
     rec = {"relax": [(int(a), b, c) for a, b, c in RELAX.findall(stdout)],
            "md5": {k: H.md5(v) for k, v in outs.items()},
            "cfg": {k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.items()},
-           "inputs": [kind, m], "shape": [1024, 512],
+           "inputs": [kind, m], "shape": [nr, nz],
            "input_md5": {"A": H.md5(A), "B": H.md5(B), "C": H.md5(Cc), "bc_init": H.md5(bc)}}
     print(name, rec["relax"], flush=True)
     return name, rec

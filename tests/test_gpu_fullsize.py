@@ -28,14 +28,15 @@ def biteq(a, b):
 
 def _inputs(g):
     kind, m = g["inputs"]
-    ins = H.test1_inputs(1024, 512) if kind == "test1" else H.member_inputs(1024, 512, m)
+    nr, nz = g["shape"]
+    ins = H.test1_inputs(nr, nz) if kind == "test1" else H.member_inputs(nr, nz, m)
     for name, arr in zip(("A", "B", "C", "bc_init"), ins):
         assert H.md5(arr) == g["input_md5"][name], "the synthetic inputs are not the ones the reference was run on"
     return ins
 
 
 @pytest.mark.parametrize("key", ["m1024x512_100000", "m1024x512_baroclinic_100000", "m1024x512_baroclinic_2000",
-                                 "bench_m0_100000", "bench_m0_baroclinic_100000"])
+                                 "bench_m0_100000", "bench_m0_baroclinic_100000", "bench_m0_4096x2048_2000"])
 def test_full_depth_anchor(key, golden_hashes):
     if key not in golden_hashes:
         pytest.skip(f"{key} not generated yet (tests/golden/make_golden_deep.py)")

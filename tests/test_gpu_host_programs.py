@@ -160,3 +160,58 @@ def test_fortran_ensemble_host_equals_single_case_runs(force_gather, tmp_path):
         iters.add(int(r[1]))
     assert len(iters) > 1, "the cases should stop at different iterations"
     assert not (tmp_path / ".xee_comm_id").exists()
+
+
+# ---- the legacy program's Fortran host (bin/xee-old-diagnose) -------------------------------------------------------
+
+OLD_HOST = ROOT / "xlab-ee-fortran_amd" / "bin" / "xee-old-diagnose"
+RELAX1 = re.compile(r"Relaxation uses\s+(\d+)\s+steps\. Final residue is\s+(\S+)\s*\.")
+
+
+@pytest.mark.parametrize("name", ["legacy_64x48_tendency", "legacy_64x48_baroall_bc"])
+def test_fortran_legacy_host_reproduces_the_legacy_binary(name, tmp_path):
+    """`xee-old-diagnose < diag.txt` with the legacy program's own config and input files (plus the `legacy_records` line:
+    read Q/F records and truncate the exchange-conversion metric the way the legacy binary does) writes EVERY file of
+    oracle/_ref/old-diagnose byte for byte, prints the same iteration counts and the same efficiency.txt numbers."""
+    import json
+    assert OLD_HOST.exists(), "build it: make -C xlab-ee-fortran_amd fortran"
+    g = np.load(H.GOLDEN / f"{name}.npz")
+    meta = json.loads(str(g["meta"]))
+    (tmp_path / "out").mkdir()
+    for k in ("A", "B", "C", "Q", "F"):
+        g["in_" + k].tofile(tmp_path / f"{k}.bin")
+    lines = [meta["mode"], "%.9e // testing_dt" % meta["testing_dt"], " ".join("%.9e" % v for v in meta["domain"]), "64 48", ".", "out",
+             "A.bin", "B.bin", "C.bin", "Q.bin", "F.bin",
+             "%d %.9e %d %.9e" % tuple(meta["psi_solver"]), "%d %.9e %d %.9e" % tuple(meta["chi_solver"])]
+    for key in ("psi_bc", "chi_bc"):
+        if "in_" + key in g.files:
+            g["in_" + key].tofile(tmp_path / f"{key}.bin")
+            lines += ["yes", f"{key}.bin"]
+        else:
+            lines.append("no")
+    lines.append("legacy_records   // Q, F as the legacy binary really holds them; INTEGER r, dr, dz in the exchange conversion")
+    (tmp_path / "diag.txt").write_text("\n".join(lines) + "\n")
+    with open(tmp_path / "diag.txt") as fin:
+        p = subprocess.run([str(OLD_HOST)], stdin=fin, cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    wrote = [k[4:] for k in g.files if k.startswith("out_")]
+    for fn in wrote:
+        got = np.fromfile(tmp_path / "out" / fn, np.float32)
+        assert got.tobytes() == np.ascontiguousarray(g["out_" + fn]).tobytes(), fn
+    assert [int(n) for n, _ in RELAX1.findall(p.stdout)] == [it for it, _ in meta["relax"]]
+    want = T.read_efficiency_raw_text(meta["efficiency_txt"]) if hasattr(T, "read_efficiency_raw_text") else None
+    got_eff = T.read_efficiency_raw(str(tmp_path / "out" / "efficiency.txt"))
+    ref_eff = {}
+    for line in meta["efficiency_txt"].splitlines():
+        if ":" in line and not line.lstrip().startswith("#"):
+            label, rest = line.split(":", 1)
+            ref_eff[label.strip()] = [float(x) for x in rest.split(",")]
+    assert set(got_eff) == set(ref_eff)
+    for label, nums in ref_eff.items():
+        if label.startswith("Time elapsed"):
+            continue
+        assert got_eff[label][0] == pytest.approx(nums[0], rel=2e-7, abs=0), label
+        if len(nums) > 1:
+            assert got_eff[label][1] == pytest.approx(nums[1], rel=4e-7, abs=0), label
+    # and the XEffReader-compatible reader sees its six keys
+    assert set(T.read_efficiency(str(tmp_path / "out" / "efficiency.txt"))) == {"semi_internal", "internal", "semi_cb1", "wtheta", "local_response", "semi_total"}

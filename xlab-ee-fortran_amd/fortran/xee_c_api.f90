@@ -11,7 +11,7 @@ integer(c_int), parameter :: XEE_BAROTROPIC = 0, XEE_BAROCLINIC = 1
 integer(c_int), parameter :: XEE_F_A = 0, XEE_F_B = 1, XEE_F_C = 2, XEE_F_BC_INIT = 3,          &
     &   XEE_F_FORCING = 4, XEE_F_PSI = 5, XEE_F_SOLVER_A = 6, XEE_F_SOLVER_B = 7,                &
     &   XEE_F_SOLVER_C = 8, XEE_F_ETA = 9, XEE_F_U = 10, XEE_F_W = 11, XEE_F_Q = 12
-integer(c_int), parameter :: XEE_SOLVE_DEFAULT = 0, XEE_SOLVE_TRACE = 4
+integer(c_int), parameter :: XEE_SOLVE_DEFAULT = 0, XEE_SOLVE_KEEP_PSI = 2, XEE_SOLVE_TRACE = 4
 
 ! xee_case_record_t, 128 bytes
 type, bind(C) :: xee_case_record
@@ -133,6 +133,89 @@ interface
         import :: c_int, c_ptr
         type(c_ptr), value :: ens
         integer(c_int), value :: first_case_id
+        integer(c_int) :: st
+    end function
+
+    ! ---- the legacy program's stages (src/old-diagnose/diagnose.f90), host arrays in the reference's layouts
+    function xee_ensemble_assemble_solver(ens, use_b) bind(C, name="xee_ensemble_assemble_solver") result(st)
+        import :: c_int, c_ptr
+        type(c_ptr), value :: ens
+        integer(c_int), value :: use_b
+        integer(c_int) :: st
+    end function
+
+    function xee_legacy_averages(rhoA_in, rhoB_in, rhoC_in, rhoA_A, rhoB_C, rhoB_B, rhoC_C, nr, nz) &
+        &                        bind(C, name="xee_legacy_averages") result(st)
+        import :: c_int, c_float
+        real(c_float), intent(in)  :: rhoA_in(*), rhoB_in(*), rhoC_in(*)
+        real(c_float), intent(out) :: rhoA_A(*), rhoB_C(*), rhoB_B(*), rhoC_C(*)
+        integer(c_int), value :: nr, nz
+        integer(c_int) :: st
+    end function
+
+    function xee_m2_from_C(rhoC_C, ra, rcuva, sin_table, m2_B, nr, nz) bind(C, name="xee_m2_from_C") result(st)
+        import :: c_int, c_float, c_ptr
+        real(c_float), intent(in)  :: rhoC_C(*), ra(*), rcuva(*)
+        type(c_ptr), value :: sin_table                     ! c_null_ptr for the cylindrical geometry
+        real(c_float), intent(out) :: m2_B(*)
+        integer(c_int), value :: nr, nz
+        integer(c_int) :: st
+    end function
+
+    function xee_JJ_B(Q_B, exner, JJ_B, nr, nz) bind(C, name="xee_JJ_B") result(st)
+        import :: c_int, c_float
+        real(c_float), intent(in)  :: Q_B(*), exner(*)
+        real(c_float), intent(out) :: JJ_B(*)
+        integer(c_int), value :: nr, nz
+        integer(c_int) :: st
+    end function
+
+    function xee_rhs_thermal(Q_B, ra, exner, rhs_O, nr, nz) bind(C, name="xee_rhs_thermal") result(st)
+        import :: c_int, c_float
+        real(c_float), intent(in)  :: Q_B(*), ra(*), exner(*)
+        real(c_float), intent(out) :: rhs_O(*)
+        integer(c_int), value :: nr, nz
+        integer(c_int) :: st
+    end function
+
+    function xee_rhs_from_B(b_B, f_O, nr, nz) bind(C, name="xee_rhs_from_B") result(st)
+        import :: c_int, c_float
+        real(c_float), intent(in)  :: b_B(*)
+        real(c_float), intent(out) :: f_O(*)
+        integer(c_int), value :: nr, nz
+        integer(c_int) :: st
+    end function
+
+    function xee_add_fields(a, b, out, n) bind(C, name="xee_add_fields") result(st)
+        import :: c_int, c_float, c_size_t
+        real(c_float), intent(in)  :: a(*), b(*)
+        real(c_float), intent(out) :: out(*)
+        integer(c_size_t), value :: n
+        integer(c_int) :: st
+    end function
+
+    function xee_integrate_weight_B(weight, ra, za, rcuva, rho, nr, nz, total) bind(C, name="xee_integrate_weight_B") result(st)
+        import :: c_int, c_float
+        real(c_float), intent(in)  :: weight(*), ra(*), za(*), rcuva(*), rho(*)
+        integer(c_int), value :: nr, nz
+        real(c_float), intent(out) :: total
+        integer(c_int) :: st
+    end function
+
+    function xee_cal_wtheta(w_A, theta_B, wtheta_B, nr, nz) bind(C, name="xee_cal_wtheta") result(st)
+        import :: c_int, c_float
+        real(c_float), intent(in)  :: w_A(*), theta_B(*)
+        real(c_float), intent(out) :: wtheta_B(*)
+        integer(c_int), value :: nr, nz
+        integer(c_int) :: st
+    end function
+
+    function xee_exchange_conversion_legacy(rpsi, rchi, rhoC, ra, za, rho, bndconv, total, nr, nz)   &
+        &                                   bind(C, name="xee_exchange_conversion_legacy") result(st)
+        import :: c_int, c_float
+        real(c_float), intent(in)  :: rpsi(*), rchi(*), rhoC(*), ra(*), za(*), rho(*)
+        real(c_float), intent(out) :: bndconv(*), total
+        integer(c_int), value :: nr, nz
         integer(c_int) :: st
     end function
 
