@@ -119,18 +119,25 @@ struct xee_ensemble {
     bool base_baro = false;      // ... of the BAROTROPIC operator (BX = BY = +0: not loaded)
     UniformVals uv{};            // coefficient planes found uniform by the last assemble / coe upload
     unsigned* uv_differs = nullptr;
-    // pipelined residual checks (solve_pipelined): the check of iteration k runs on `cstream` while
-    // the sweeps of the next block already run on `stream`
-    hipStream_t cstream = nullptr;
-    hipEvent_t evE[2] = {nullptr, nullptr}, evF[2] = {nullptr, nullptr};      // sweep-side / check-side, by check parity
-    hipEvent_t evB[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};          // sweep block begin/end, by check parity
-    float* res2 = nullptr;       // second residual plane (checks alternate res / res2)
-    float* snap = nullptr;       // 2 x members planes: the iterate right after each check iteration
-    MemberState* st_host2 = nullptr;   // pinned, 2 x members
+    // pipelined residual checks (solve_pipelined): the check of iteration k runs on a check stream while the sweeps of
+    // the next block(s) already run on `stream`.  Resources are per SLOT (check k uses slot k % (depth + 1)) or per check
+    // stream (check k runs on cstream[k % depth]); depth is 1 for large batches and 2 for small ones, whose check (a
+    // chain of latency-bound kernels) takes longer than a block of sweeps.
+    hipStream_t cstream[2] = {nullptr, nullptr};
+    hipEvent_t evE[3] = {nullptr, nullptr, nullptr}, evF[3] = {nullptr, nullptr, nullptr};   // sweep-side / check-side, by slot
+    hipEvent_t evB[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};     // sweep block begin/end, by slot
+    float* res2 = nullptr;       // residual planes of slots 1 and 2 (slot 0 is `res`); res3 only at depth 2
+    float* res3 = nullptr;
+    float* snap = nullptr;       // 3 x members planes: the iterate right after each check iteration, by slot
+    MemberState* st_host2 = nullptr;   // pinned, 3 x members: the member states after a check, by slot (written by the device)
+    void* ex_ws2 = nullptr;      // second check stream's norm workspace, sums and slow counters (depth 2 only)
+    float* sums2 = nullptr;
+    int* ex_slow2 = nullptr;
     int* redo = nullptr;               // tile list of k_sweep_q's residual-writing launches (xee_sweepq.hip)
-    MemberState* st_view = nullptr;    // the sweeps' view of the member states in the pipelined driver: refreshed on the
-                                       // sweep stream between launches only, so that a workgroup's early exit on `active`
-                                       // is uniform although the state machine clears the flag concurrently on `cstream`
+    MemberState* st_view = nullptr;    // 4 x members: the sweeps' VIEWS of the member states in the pipelined driver.  The
+                                       // state machine of check k writes view k % 4 (on a check stream); the sweeps read the
+                                       // view of a check the host has seen finish and switch between launches only, so that
+                                       // a workgroup's early exit on `active` is uniform although flags are cleared concurrently
 };
 
 namespace {
@@ -395,11 +402,15 @@ int xee_ensemble_destroy(xee_ensemble_t* e)
     if (e->ex_slow) hipFree(e->ex_slow);
     if (e->uv_differs) hipFree(e->uv_differs);
     if (e->base) hipFree(e->base);
-    if (e->cstream) { hipStreamSynchronize(e->cstream); hipStreamDestroy(e->cstream); }
+    for (auto& c : e->cstream) if (c) { hipStreamSynchronize(c); hipStreamDestroy(c); }
     for (auto& ev : e->evE) if (ev) hipEventDestroy(ev);
     for (auto& ev : e->evF) if (ev) hipEventDestroy(ev);
     for (auto& pr : e->evB) for (auto& ev : pr) if (ev) hipEventDestroy(ev);
     if (e->res2) hipFree(e->res2);
+    if (e->res3) hipFree(e->res3);
+    if (e->ex_ws2) hipFree(e->ex_ws2);
+    if (e->sums2) hipFree(e->sums2);
+    if (e->ex_slow2) hipFree(e->ex_slow2);
     if (e->snap) hipFree(e->snap);
     if (e->st_host2) hipHostFree(e->st_host2);
     if (e->st_view) hipFree(e->st_view);
@@ -598,39 +609,75 @@ int xee_ensemble_assemble_solver(xee_ensemble_t* e, int use_b)
 namespace {
 
 // solve_elliptic with the residual checks PIPELINED behind the sweeps.  The check of iteration k
-// (exact norm + state machine) runs on e->cstream while the next block of sweeps already runs on
+// (exact norm + state machine) runs on a check stream while the next block(s) of sweeps already run on
 // e->stream; a member found to have stopped at check k has, by then, been iterated further, so the
-// iterate right after every check iteration is kept in a snapshot plane (two slots, alternating)
-// and its result is taken from there.  Sweeps skip a member as soon as the state machine has
-// cleared its `active` flag on the device -- the host only needs to learn it to stop enqueuing.
-// Same values as the synchronous driver (tests run both).
+// iterate right after every check iteration is kept in a snapshot plane (one per slot)
+// and its result is taken from there.  Sweeps skip a member as soon as they are shown a view of the member states
+// in which its `active` flag is cleared.  Same values as the synchronous driver (tests run both).
+//
+// Depth.  A large batch keeps the host ONE check behind the sweeps (two slots, one check stream): its block of sweeps
+// takes milliseconds and the check fits in its shadow.  For a small batch the check -- eight dependent, latency-bound
+// kernels, ~165 us for one 1024x512 case, 80 of them the serial walk -- takes LONGER than the block of sweeps it hides
+// behind (~125 us), and the sweep stream stood idle waiting for the host (profiles/r02, timeline of the `single`
+// workload).  There the host stays TWO checks behind (three slots) and consecutive checks alternate between two
+// check streams with their own workspaces, so that norm k overlaps norm k-1; only the state machine is chained
+// (check k's update waits for check k-1's).
+//
+// What the sweep stream carries per check, besides sweeps, decides a small batch's speed (each event record or copy
+// is a packet of ~5 us between 9 us kernels), so: the state machine itself publishes the member states (a device view
+// per check for the sweeps, a pinned host copy for this loop -- no copy kernels); a slot is reused only after the HOST
+// has seen its previous check finish (no stream wait needed); and the per-block begin/end events that time the sweeps
+// are recorded for large batches only -- a small batch's `sweep_ms` is the span of the sweep stream from the first
+// launch to the last (it carries nothing but sweeps).
 int solve_pipelined(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float alpha, int tb_T)
 {
     const Grid& g = e->g;
     hipStream_t s = e->stream;
-    if (!e->cstream) {
-        HIPCHK(create_stream(&e->cstream, false));
+    // The norm's wide kernels (chunk sums, scans, summaries: ~75 us for 32 cases) stay on the sweep stream for a large
+    // batch -- beside the sweeps they took compute units from every launch of the next block (+12 % per sweep launch,
+    // profiles/r02) -- and only the serial walk (one wave per member) and the state machine run in the shadow of the
+    // sweeps.  A small batch leaves the machine half empty anyway: there the whole norm runs beside the sweeps.
+    const bool wide_on_sweep_stream = !e->exact_serial && (size_t)g.members * g.nx * g.ny >= ((size_t)4 << 20);
+    const int D = wide_on_sweep_stream ? 1 : 2;   // checks in flight behind the sweeps
+    const int NS = D + 1;                         // slots (residual plane, snapshot, events, host copy of the states)
+    constexpr int NV = 4;                         // views of the member states (see below)
+    const bool block_events = wide_on_sweep_stream;
+    if (!e->cstream[0]) {
+        HIPCHK(create_stream(&e->cstream[0], false));
         for (auto& ev : e->evE) HIPCHK(hipEventCreate(&ev));
         for (auto& ev : e->evF) HIPCHK(hipEventCreate(&ev));
         for (auto& pr : e->evB) for (auto& ev : pr) HIPCHK(hipEventCreate(&ev));
-        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->st_host2), sizeof(MemberState) * 2 * g.members));
-        HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->st_view), sizeof(MemberState) * g.members));
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->st_host2), sizeof(MemberState) * 3 * g.members));
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->st_view), sizeof(MemberState) * NV * g.members));
     }
-    // (a stale view only costs work: a member found stopped keeps iterating until the next refresh and its result is
+    if (D == 2 && !e->cstream[1]) {
+        HIPCHK(create_stream(&e->cstream[1], false));
+        HIPCHK(hipMalloc(&e->ex_ws2, exact_ws_bytes(g)));
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->sums2), sizeof(float) * g.members));
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->ex_slow2), sizeof(int) * g.members));
+    }
+    // Views.  Check j's state machine writes view j % NV.  The sweeps start on view NV-1 (a copy of the initial states)
+    // and, at the residual-writing launch of check k, move to the view of check k-1-D: the newest check the host has
+    // digested, so it is complete and no stream wait is needed.  Until the next move that view is only read: the state
+    // machines that may run meanwhile are those of checks k-D .. k, which write other views (NV = 4 > D + 1).
+    // (a stale view only costs work: a member found stopped keeps iterating until the sweeps see it and its result is
     // taken from the snapshot of its stopping check anyway)
-    auto refresh_view = [&]() -> int {
-        HIPCHK(hipMemcpyAsync(e->st_view, e->st, sizeof(MemberState) * g.members, hipMemcpyDeviceToDevice, s));
-        return XEE_OK;
-    };
-    XCHK(refresh_view());
+    for (int v = 0; v < NV; ++v)
+        HIPCHK(hipMemcpyAsync(e->st_view + (size_t)v * g.members, e->st, sizeof(MemberState) * g.members, hipMemcpyDeviceToDevice, s));
+    const MemberState* view = e->st_view + (size_t)(NV - 1) * g.members;
     XCHK(alloc_planes(e, &e->res2));
-    XCHK(alloc_planes(e, &e->snap, 2));
-    hipStream_t c = e->cstream;
-    float* resbuf[2] = {e->res, e->res2};
-    float* snapbuf[2] = {e->snap, e->snap + (size_t)g.members * g.plane};
-    // both snapshot slots start as full copies of the first guess: the rim never changes, and a residual-writing sweep
+    if (D == 2) XCHK(alloc_planes(e, &e->res3));
+    XCHK(alloc_planes(e, &e->snap, 3));
+    hipStream_t cst[2] = {e->cstream[0], e->cstream[D - 1]};
+    void* wsb[2] = {e->ex_ws, D == 2 ? e->ex_ws2 : e->ex_ws};
+    float* sumb[2] = {e->sums, D == 2 ? e->sums2 : e->sums};
+    int* slowb[2] = {e->ex_slow, D == 2 ? e->ex_slow2 : e->ex_slow};
+    float* resbuf[3] = {e->res, e->res2, e->res3};
+    float* snapbuf[3] = {e->snap, e->snap + (size_t)g.members * g.plane, e->snap + 2 * (size_t)g.members * g.plane};
+    // every snapshot slot starts as a full copy of the first guess: the rim never changes, and a residual-writing sweep
     // launch that fills the snapshot itself only stores interior points
     launch_copy2(g, e->psi[e->cur], snapbuf[0], snapbuf[1], s);
+    if (D == 2) launch_copy2(g, e->psi[e->cur], snapbuf[2], nullptr, s);
 
     int cur = e->cur;
     std::vector<int> stop_slot(g.members, -1);    // snapshot slot holding a stopped member's result
@@ -638,22 +685,28 @@ int solve_pipelined(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float 
     e->timing = xee_timing_t{};
     HIPCHK(hipEventRecord(e->ev[0], s));
     int cnt = 0, k = 0;                           // k = number of checks enqueued
+    int digested = 0;                             // ... and of checks whose outcome the host has looked at
     int final_check = -1;                         // index of a check that coincides with max_iter
-    bool all_done = (max_iter == 0), block_open = false;
+    bool all_done = (max_iter == 0), block_open = false, sweeps_end_recorded = false;
 
-    // digest the result of check j (its pipeline has finished when evF[j&1] has)
-    auto digest = [&](int j) -> int {
-        HIPCHK(hipEventSynchronize(e->evF[j & 1]));
-        float ms = 0.f;
-        HIPCHK(hipEventElapsedTime(&ms, e->evB[j & 1][0], e->evB[j & 1][1]));
-        e->timing.sweep_ms += ms;
-        const MemberState* sh = e->st_host2 + (size_t)(j & 1) * g.members;
-        all_done = true;
-        for (int m = 0; m < g.members; ++m) {
-            if (active[m] && !sh[m].active) { active[m] = 0; stop_slot[m] = j & 1; }
-            if (sh[m].active) all_done = false;
+    // digest the results of the checks up to j, in order (check j's pipeline has finished when its slot's evF has)
+    auto digest_upto = [&](int j) -> int {
+        for (; digested <= j; ++digested) {
+            const int sl = digested % NS;
+            HIPCHK(hipEventSynchronize(e->evF[sl]));
+            if (block_events) {
+                float ms = 0.f;
+                HIPCHK(hipEventElapsedTime(&ms, e->evB[sl][0], e->evB[sl][1]));
+                e->timing.sweep_ms += ms;
+            }
+            const MemberState* sh = e->st_host2 + (size_t)sl * g.members;
+            all_done = true;
+            for (int m = 0; m < g.members; ++m) {
+                if (active[m] && !sh[m].active) { active[m] = 0; stop_slot[m] = sl; }
+                if (sh[m].active) all_done = false;
+            }
+            memcpy(e->st_host, sh, sizeof(MemberState) * g.members);
         }
-        memcpy(e->st_host, sh, sizeof(MemberState) * g.members);
         return XEE_OK;
     };
 
@@ -663,89 +716,97 @@ int solve_pipelined(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float 
         const int n = (target - cnt) < tb_T ? (target - cnt) : tb_T;
         cnt += n;
         const bool check = cnt == next_check, last = cnt == max_iter;
-        const int pk = k & 1;
-        if (!block_open) { HIPCHK(hipEventRecord(e->evB[pk][0], s)); block_open = true; }
-        if (check && k >= 2) { HIPCHK(hipStreamWaitEvent(s, e->evF[pk], 0)); XCHK(refresh_view()); }   // res/snap slot pk is free again
+        const int sl = k % NS, ci = k % D;
+        if (block_events && !block_open) { HIPCHK(hipEventRecord(e->evB[sl][0], s)); block_open = true; }
+        // slot sl last belonged to check k-NS = k-1-D, which the host digested at the end of the previous check's
+        // iteration of this loop: it is free, and its check's view is the newest one that is safe to show the sweeps
+        if (check && k >= NS) view = e->st_view + (size_t)((k - NS) % NV) * g.members;
         bool snapped = false;
         if (n == 1)
-            launch_sweep(g, e->psi[cur], e->psi[cur ^ 1], e->coe, e->f, check ? resbuf[pk] : nullptr, e->st_view, alpha, s);
+            launch_sweep(g, e->psi[cur], e->psi[cur ^ 1], e->coe, e->f, check ? resbuf[sl] : nullptr, view, alpha, s);
         else
-            snapped = launch_blocked(e, e->psi[cur], e->psi[cur ^ 1], check ? resbuf[pk] : nullptr, alpha, n, e->st_view,
-                                     check ? snapbuf[pk] : nullptr);
+            snapped = launch_blocked(e, e->psi[cur], e->psi[cur ^ 1], check ? resbuf[sl] : nullptr, alpha, n, view,
+                                     check ? snapbuf[sl] : nullptr);
         cur ^= 1;
         e->timing.sweep_launches += 1;
         e->timing.iterations += n;
         if (check) {
-            HIPCHK(hipEventRecord(e->evB[pk][1], s));
-            block_open = false;
-            if (!snapped) launch_copy_active(g, e->psi[cur], snapbuf[pk], e->st_view, s);   // the iterate this check belongs to
-            // The norm's wide kernels (chunk sums, scans, summaries: ~75 us) stay on the sweep stream -- beside the
-            // sweeps they took compute units from every launch of the next block (+12 % per sweep launch, profiles/r02)
-            // -- and only the serial walk (one wave per member) and the state machine run in the shadow of the sweeps.
-            // Their workspace is shared between checks: check k-1 must have finished with it.
-            // (a small batch leaves the machine half empty anyway: there the whole norm stays beside the sweeps, whose
-            // block of 100 iterations is shorter than the wide kernels would add)
-            const bool wide_on_sweep_stream = !e->exact_serial && (size_t)g.members * g.nx * g.ny >= ((size_t)4 << 20);
+            hipStream_t c = cst[ci];
+            if (block_events) { HIPCHK(hipEventRecord(e->evB[sl][1], s)); block_open = false; }
+            if (!snapped) launch_copy_active(g, e->psi[cur], snapbuf[sl], view, s);   // the iterate this check belongs to
             if (wide_on_sweep_stream) {
-                if (k >= 1) HIPCHK(hipStreamWaitEvent(s, e->evF[(k - 1) & 1], 0));
-                launch_exact_sumsq_prepare(g, resbuf[pk], e->ex_ws, e->st_view, s);
+                // the workspace is shared between checks: check k-1 must have finished with it
+                if (k >= 1) HIPCHK(hipStreamWaitEvent(s, e->evF[(k - 1) % NS], 0));
+                launch_exact_sumsq_prepare(g, resbuf[sl], wsb[ci], view, s);
             }
-            HIPCHK(hipEventRecord(e->evE[pk], s));
-            HIPCHK(hipStreamWaitEvent(c, e->evE[pk], 0));
-            if (e->exact_serial) launch_seqsum(g, resbuf[pk], 1, g.nx - 1, 1, g.ny - 1, true, e->sums, e->st, c);
-            else if (wide_on_sweep_stream) launch_exact_sumsq_walk(g, resbuf[pk], e->ex_ws, e->sums, e->ex_slow, e->st, c);
-            else launch_exact_sumsq(g, resbuf[pk], e->ex_ws, e->sums, e->ex_slow, e->st, c);
+            HIPCHK(hipEventRecord(e->evE[sl], s));
+            HIPCHK(hipStreamWaitEvent(c, e->evE[sl], 0));
+            if (e->exact_serial) launch_seqsum(g, resbuf[sl], 1, g.nx - 1, 1, g.ny - 1, true, sumb[ci], e->st, c);
+            else if (wide_on_sweep_stream) launch_exact_sumsq_walk(g, resbuf[sl], wsb[ci], sumb[ci], slowb[ci], e->st, c);
+            else launch_exact_sumsq(g, resbuf[sl], wsb[ci], sumb[ci], slowb[ci], e->st, c);
+            // the state machine is sequential in the checks: at depth 2 check k-1 ran on the other stream
+            if (D == 2 && k >= 1) HIPCHK(hipStreamWaitEvent(c, e->evF[(k - 1) % NS], 0));
             cp.cnt = cnt;
             cp.is_last = last ? 1 : 0;
-            launch_conv_update(g, e->sums, e->st, cp, c);
-            HIPCHK(hipMemcpyAsync(e->st_host2 + (size_t)pk * g.members, e->st, sizeof(MemberState) * g.members,
-                                  hipMemcpyDeviceToHost, c));
-            HIPCHK(hipEventRecord(e->evF[pk], c));
+            launch_conv_update(g, sumb[ci], e->st, cp, c, e->st_view + (size_t)(k % NV) * g.members,
+                               e->st_host2 + (size_t)sl * g.members);
+            HIPCHK(hipEventRecord(e->evF[sl], c));
             e->timing.check_launches += 1;
             XCHK(check_launch("sweep/check"));
             if (last) final_check = k;
-            if (k >= 1) XCHK(digest(k - 1));                                 // one check behind the sweeps
+            if (k >= D) XCHK(digest_upto(k - D));                            // D checks behind the sweeps
             ++k;
         } else if (last) {
             // max_iter is not a check iteration: every earlier check must be settled before :242-248 applies
-            if (k >= 1) XCHK(digest(k - 1));
-            HIPCHK(hipStreamSynchronize(c));
+            XCHK(digest_upto(k - 1));
+            for (int i = 0; i < D; ++i) HIPCHK(hipStreamSynchronize(cst[i]));
             launch_finalize(g, e->st, max_iter, s);
             HIPCHK(hipMemcpyAsync(e->st_host, e->st, sizeof(MemberState) * g.members, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipEventRecord(e->ev[2], s));
+            sweeps_end_recorded = true;
             HIPCHK(hipStreamSynchronize(s));
             XCHK(check_launch("finalize"));
             for (int m = 0; m < g.members; ++m) active[m] = 0;               // their result is psi[cur] itself
             all_done = true;
         }
     }
-    if (k >= 1 && final_check == k - 1) XCHK(digest(k - 1));                  // the check at max_iter
-    else if (k >= 1 && !all_done) XCHK(digest(k - 1));
-    HIPCHK(hipStreamSynchronize(c));
+    if (!sweeps_end_recorded) HIPCHK(hipEventRecord(e->ev[2], s));           // the end of the sweeps on their stream
+    // the checks still in flight: their outcome decides whose result is a snapshot (a member may have stopped at any
+    // of them; whatever was enqueued after its stopping check is discarded below)
+    XCHK(digest_upto(k - 1));
+    for (int i = 0; i < D; ++i) HIPCHK(hipStreamSynchronize(cst[i]));
     HIPCHK(hipEventRecord(e->ev[1], s));
     if (max_iter == 0) HIPCHK(hipMemcpyAsync(e->st_host, e->st, sizeof(MemberState) * g.members, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, e->ev[0], e->ev[1]));
     e->timing.solve_ms = ms;
+    if (!block_events) {
+        HIPCHK(hipEventElapsedTime(&ms, e->ev[0], e->ev[2]));
+        e->timing.sweep_ms = ms;
+    }
 
     // :259-264  results into one plane.  A member that stopped at a check has been iterated further
     // while its check was in flight (unless that check was the very last thing enqueued): take its snapshot.
     const bool tail_clean = (final_check >= 0 && final_check == k - 1);       // nothing ran after the last check
     for (int m = 0; m < g.members; ++m) {
         if (stop_slot[m] < 0) continue;                                       // ended by finalize: psi[cur] is it
-        if (tail_clean && stop_slot[m] == ((k - 1) & 1) && e->st_host[m].iters == max_iter) continue;
+        if (tail_clean && stop_slot[m] == ((k - 1) % NS) && e->st_host[m].iters == max_iter) continue;
         HIPCHK(hipMemcpyAsync(e->psi[cur] + (size_t)m * g.plane, snapbuf[stop_slot[m]] + (size_t)m * g.plane,
                               sizeof(float) * g.plane, hipMemcpyDeviceToDevice, s));
     }
     if (e->redo) { int n = 0; HIPCHK(hipMemcpyAsync(&n, e->redo + sweep_q_redo_ints(g) - 1, sizeof(int), hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s)); e->timing.redo_tiles = n; }
-    // XEE_F_RESIDUAL = the residual plane of each member's LAST check (include/xee.h): checks alternated between two
-    // planes; a stopped member's is the one of its stopping check, everyone else's the one of the last check enqueued
+    // XEE_F_RESIDUAL = the residual plane of each member's LAST check (include/xee.h): checks rotated through the
+    // slots' planes; a stopped member's is the one of its stopping check, everyone else's the one of the last check enqueued
     for (int m = 0; m < g.members && k >= 1; ++m) {
-        const int slot = stop_slot[m] >= 0 ? stop_slot[m] : ((k - 1) & 1);
-        if (slot == 1)
-            HIPCHK(hipMemcpyAsync(e->res + (size_t)m * g.plane, e->res2 + (size_t)m * g.plane, sizeof(float) * g.plane,
+        const int slot = stop_slot[m] >= 0 ? stop_slot[m] : ((k - 1) % NS);
+        if (slot != 0)
+            HIPCHK(hipMemcpyAsync(e->res + (size_t)m * g.plane, resbuf[slot] + (size_t)m * g.plane, sizeof(float) * g.plane,
                                   hipMemcpyDeviceToDevice, s));
     }
+    // the slow-chunk counters of the last check, where callers look for them
+    if (D == 2 && k >= 1 && ((k - 1) % D) == 1 && !e->exact_serial)
+        HIPCHK(hipMemcpyAsync(e->ex_slow, e->ex_slow2, sizeof(int) * g.members, hipMemcpyDeviceToDevice, s));
     HIPCHK(hipStreamSynchronize(s));
     e->cur = cur;
     return XEE_OK;

@@ -136,7 +136,8 @@ void launch_residual(const Grid& g, const float* psi, const float* coe, const fl
 // sequential fp32 sum, reference loop order (i outer, j inner), of T or T*T over a sub-rectangle
 void launch_seqsum(const Grid& g, const float* T, int i0, int i1, int j0, int j1, bool square,
                    float* out_sums, const MemberState* st, hipStream_t s);
-void launch_conv_update(const Grid& g, const float* sums, MemberState* st, ConvParams p, hipStream_t s);
+void launch_conv_update(const Grid& g, const float* sums, MemberState* st, ConvParams p, hipStream_t s,
+                        MemberState* view = nullptr /* device */, MemberState* host_out = nullptr /* pinned host */);
 void launch_finalize(const Grid& g, MemberState* st, int max_iter, hipStream_t s);
 void launch_state_init(const Grid& g, MemberState* st, hipStream_t s);
 void launch_copy2(const Grid& g, const float* src, float* dst0, float* dst1, hipStream_t s);

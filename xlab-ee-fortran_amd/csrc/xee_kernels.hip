@@ -459,13 +459,19 @@ void launch_residual(const Grid& g, const float* psi, const float* coe, const fl
 }
 
 // convergence state machine, elliptic_tools.f90:199-234 and :242-256; one lane per member
+// (`view` / `host_out`, when given, receive the state of EVERY member after this check: the pipelined driver's per-check
+// view for the sweeps and its pinned host copy, xee_api.hip solve_pipelined)
 __global__ void k_conv_update(Grid g, const float* __restrict__ sums, MemberState* __restrict__ st,
-                              ConvParams p)
+                              ConvParams p, MemberState* __restrict__ view, MemberState* __restrict__ host_out)
 {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= g.members) return;
     MemberState s = st[m];
-    if (!s.active) return;
+    if (!s.active) {
+        if (view) view[m] = s;
+        if (host_out) host_out[m] = s;
+        return;
+    }
     const float err_now = sqrtf(sums[m] / (float)p.n_interior);          // :199
     float ratio = (s.err_before - err_now) / s.err_before;                // :201
     if (p.debug == 2) printf("Iter: %8d, err_now: %12.3E, ratio: %12.3E\n", p.cnt, err_now, ratio);
@@ -487,6 +493,8 @@ __global__ void k_conv_update(Grid g, const float* __restrict__ sums, MemberStat
     if (p.is_last) { stop = true; s.err_bits |= 1; }                      // :242-248
     if (stop) { s.active = 0; s.iters = p.cnt; }
     st[m] = s;
+    if (view) view[m] = s;
+    if (host_out) host_out[m] = s;
 }
 
 // max_iter reached on an iteration that is not a check iteration (:242-248)
@@ -882,9 +890,10 @@ void launch_seqsum(const Grid& g, const float* T, int i0, int i1, int j0, int j1
         hipLaunchKernelGGL((k_seqsum<false>), dim3(g.members), dim3(256), lds, s, g, T, i0, i1, j0, j1, tc, cs, out_sums, st);
 }
 
-void launch_conv_update(const Grid& g, const float* sums, MemberState* st, ConvParams p, hipStream_t s)
+void launch_conv_update(const Grid& g, const float* sums, MemberState* st, ConvParams p, hipStream_t s,
+                        MemberState* view, MemberState* host_out)
 {
-    hipLaunchKernelGGL(k_conv_update, dim3((g.members + 63) / 64), dim3(64), 0, s, g, sums, st, p);
+    hipLaunchKernelGGL(k_conv_update, dim3((g.members + 63) / 64), dim3(64), 0, s, g, sums, st, p, view, host_out);
 }
 
 void launch_finalize(const Grid& g, MemberState* st, int max_iter, hipStream_t s)
