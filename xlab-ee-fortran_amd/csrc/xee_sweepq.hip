@@ -267,8 +267,9 @@ __device__ __forceinline__ bool fast_tile(const Grid& g, const TileGeom& tg, flo
     // (Measured alternatives, tools/probe_q.hip: the barrier costs about as much as a step's arithmetic, but
     // per-neighbour flags in LDS instead are worse still: waves that spin on a flag take issue slots from the
     // wave they wait for.)
-    auto step = [&](const f2 (&src)[H2], f2 (&dst)[H2], int t, auto last_tag) {
+    auto step = [&](const f2 (&src)[H2], f2 (&dst)[H2], int t, auto last_tag, auto track_tag) {
         constexpr bool LAST = decltype(last_tag)::value;      // the launch's final step (keeps the residual)
+        constexpr bool TRACK_MIN = decltype(track_tag)::value; // the wave needs the running minimum of |a| (see below)
         const int par = t & 1;
         __syncthreads();
         const float below = (w > 0) ? edge[par][0][w - 1][lane] : 0.0f;
@@ -278,7 +279,7 @@ __device__ __forceinline__ bool fast_tile(const Grid& g, const TileGeom& tg, flo
             const f2 a = ALPHA1 ? Rv : alpha2 * Rv;
             dst[k] = src[k] + quotient_q2(a, c[K5][k], y1[k]);         // :238, -d = coe5
             amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(a.x)), __builtin_fabsf(a.y));
-            amin = __builtin_fminf(__builtin_fminf(amin, __builtin_fabsf(a.x)), __builtin_fabsf(a.y));
+            if constexpr (TRACK_MIN) amin = __builtin_fminf(__builtin_fminf(amin, __builtin_fabsf(a.x)), __builtin_fabsf(a.y));
             if constexpr (WRITE_R && LAST) rl[k] = Rv;
         };
         if constexpr (BARO) {
@@ -332,37 +333,56 @@ __device__ __forceinline__ bool fast_tile(const Grid& g, const TileGeom& tg, flo
     };
     edge[0][0][w][lane] = p[H2 - 1].y;
     edge[0][1][w][lane] = p[0].x;
-    int t = 0;
+    // Where zeros may pass (see "Zero residuals" in the header) the lower bound holds by construction and the running
+    // minimum is never looked at: a WAVE whose lanes all are in that position runs the instance of the loop that does not
+    // keep it (one v_min3 per pair and step less, ~5 % of the loop).  The choice is wave-uniform; both instances meet
+    // the workgroup's barriers the same number of times.
+    const float a_lo = __builtin_fmaxf(0x1p-100f, dmax * 0x1p-120f);
+    const bool zero_ok = !neg_zero_psi && __builtin_fabsf(alpha) * fmin * 0x1p-26f >= a_lo;
     bool in_q;
-    if constexpr (WRITE_R) {
-        // the final step is its own instance (it keeps the residual): T - 1 or T - 2 steps in pairs first
-        for (; t + 2 < T; t += 2) {
-            step(p, q, t, std::false_type{});
-            step(q, p, t + 1, std::false_type{});
-        }
-        in_q = t + 1 >= T;
-        if (in_q) step(p, q, t, std::true_type{});
-        else { step(p, q, t, std::false_type{}); step(q, p, t + 1, std::true_type{}); }
-    } else {
-        for (; t + 1 < T; t += 2) {
-            step(p, q, t, std::false_type{});
-            step(q, p, t + 1, std::false_type{});
-        }
-        in_q = t < T;                                     // odd T: one more step, which writes q
-        if (in_q) step(p, q, t, std::false_type{});
+    // (the loop is written out once per instance -- a macro, not a lambda around `step`: with one more closure level the
+    // iterate's register arrays were left in scratch memory)
+#define XEE_Q_RUN(TRACK)                                                                                           \
+    {                                                                                                              \
+        int t = 0;                                                                                                 \
+        if constexpr (WRITE_R) {                                                                                   \
+            /* the final step is its own instance (it keeps the residual): T - 1 or T - 2 steps in pairs first */  \
+            for (; t + 2 < T; t += 2) {                                                                            \
+                step(p, q, t, std::false_type{}, TRACK);                                                           \
+                step(q, p, t + 1, std::false_type{}, TRACK);                                                       \
+            }                                                                                                      \
+            in_q = t + 1 >= T;                                                                                     \
+            if (in_q) step(p, q, t, std::true_type{}, TRACK);                                                      \
+            else { step(p, q, t, std::false_type{}, TRACK); step(q, p, t + 1, std::true_type{}, TRACK); }          \
+        } else {                                                                                                   \
+            for (; t + 1 < T; t += 2) {                                                                            \
+                step(p, q, t, std::false_type{}, TRACK);                                                           \
+                step(q, p, t + 1, std::false_type{}, TRACK);                                                       \
+            }                                                                                                      \
+            in_q = t < T;                                     /* odd T: one more step, which writes q */           \
+            if (in_q) step(p, q, t, std::false_type{}, TRACK);                                                     \
+        }                                                                                                          \
+    }
+    if (__builtin_amdgcn_ballot_w64(!zero_ok) != 0) XEE_Q_RUN(std::true_type{})
+    else XEE_Q_RUN(std::false_type{})
+#undef XEE_Q_RUN
+    // the result into p whichever array the last step wrote (R/2 moves once per launch: with a choice between the two
+    // ARRAYS further down, and two instances of the loop above, the compiler kept both arrays in scratch memory)
+    if (in_q) {
+#pragma unroll
+        for (int k = 0; k < H2; ++k) p[k] = q[k];
     }
     stamp<STAMP>(tg, 3);                                  // T steps done
 
     {
         bool ok = dmin >= 0x1p-120f && dmax <= 0x1p120f;
-        const float a_lo = __builtin_fmaxf(0x1p-100f, dmax * 0x1p-120f);
         const float a_hi = __builtin_fminf(0x1p100f, dmin * 0x1p94f);
-        // (see "Zero residuals" in the header: where every non-zero |a| is above a_lo by construction, zeros may pass)
-        const bool zero_ok = !neg_zero_psi && __builtin_fabsf(alpha) * fmin * 0x1p-26f >= a_lo;
+        // (see "Zero residuals" in the header: where every non-zero |a| is above a_lo by construction, zeros may pass --
+        // and a wave of such lanes only did not keep amin, which still is +inf)
         ok = ok && (zero_ok || amin >= a_lo) && amax <= a_hi;
 #pragma unroll
         for (int k = 0; k < H2; ++k) {
-            const f2 v = in_q ? q[k] : p[k];
+            const f2 v = p[k];
             ok = ok && __builtin_fabsf(v.x) <= FLT_MAX && __builtin_fabsf(v.y) <= FLT_MAX;   // false for NaN too
         }
         // one-barrier vote (__syncthreads_and takes three): a flag per wave, then every wave looks at all of them
@@ -386,7 +406,7 @@ __device__ __forceinline__ bool fast_tile(const Grid& g, const TileGeom& tg, flo
             const bool row_int = INNER || (gy >= 1 && gy <= g.ny - 2);
             if (vy && row_int) {
                 const int o = gy * g.pitch * 4;
-                const f2 v = in_q ? q[k] : p[k];
+                const f2 v = p[k];
                 bstore(outr, sx, o, r < H2 ? v.x : v.y);
                 if constexpr (WRITE_R) {
                     bstore(plane_rsrc(res + mo, g), sx, o, r < H2 ? rl[k].x : rl[k].y);
