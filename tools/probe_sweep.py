@@ -38,7 +38,7 @@ def main():
             for _ in range(ROUNDS):
                 for i, opts in enumerate(cfgs):
                     for k in ("tb_T", "kernel", "tile"):
-                        e.set_option(k, {"tb_T": 6}.get(k, 0))
+                        e.set_option(k, {"tb_T": 8}.get(k, 0))
                     for k, v in opts.items():
                         e.set_option(k, v)
                     ms, n = e.time_sweeps(iters, 1)
