@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -710,30 +711,74 @@ int solve_pipelined(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float 
         return XEE_OK;
     };
 
+    // Graphs.  A small batch is bound by how fast the host enqueues (one 1024x512 case: 13 launches of ~9 us per block
+    // and eight more per check): a whole block -- the launches between two checks -- is captured once per distinct set
+    // of arguments (ping-pong phase x slot x view: at most 2 x 3 x 4) and replayed as a graph.
+    struct BlockGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; bool snapped = false; int launches = 0; };
+    struct GraphCache {
+        std::map<int, BlockGraph> m;
+        ~GraphCache() { for (auto& kv : m) { if (kv.second.exec) hipGraphExecDestroy(kv.second.exec); if (kv.second.graph) hipGraphDestroy(kv.second.graph); } }
+    } graphs;
+    const bool use_graphs = !wide_on_sweep_stream && tb_T > 1 && cs > tb_T && max_iter / cs >= 64;
+    if (use_graphs && !e->redo && e->have_base && e->opts.kernel != 1 && e->opts.kernel != 2) {
+        // (launch_blocked allocates the tile list on first use: not inside a capture)
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->redo), sizeof(int) * sweep_q_redo_ints(g)));
+        HIPCHK(hipMemsetAsync(e->redo, 0, sizeof(int) * sweep_q_redo_ints(g), s));
+    }
+    // the launches from iteration `from` up to `target` (a check iteration gets the residual plane and the snapshot)
+    auto enqueue_sweeps = [&](int from, int target, bool to_check, int sl, int* cur_io, bool* snapped, int* launches) {
+        int c2 = from;
+        *snapped = false; *launches = 0;
+        while (c2 < target) {
+            const int n = (target - c2) < tb_T ? (target - c2) : tb_T;
+            c2 += n;
+            const bool check = to_check && c2 == target;
+            if (n == 1)
+                launch_sweep(g, e->psi[*cur_io], e->psi[*cur_io ^ 1], e->coe, e->f, check ? resbuf[sl] : nullptr, view, alpha, s);
+            else if (launch_blocked(e, e->psi[*cur_io], e->psi[*cur_io ^ 1], check ? resbuf[sl] : nullptr, alpha, n, view,
+                                    check ? snapbuf[sl] : nullptr))
+                *snapped = true;
+            *cur_io ^= 1;
+            *launches += 1;
+        }
+        if (to_check && !*snapped) launch_copy_active(g, e->psi[*cur_io], snapbuf[sl], view, s);   // the iterate this check belongs to
+    };
+
     while (cnt < max_iter && !all_done) {
         const int next_check = (cnt / cs + 1) * cs;
         const int target = next_check < max_iter ? next_check : max_iter;
-        const int n = (target - cnt) < tb_T ? (target - cnt) : tb_T;
-        cnt += n;
-        const bool check = cnt == next_check, last = cnt == max_iter;
+        const bool check = target == next_check, last = target == max_iter;
         const int sl = k % NS, ci = k % D;
         if (block_events && !block_open) { HIPCHK(hipEventRecord(e->evB[sl][0], s)); block_open = true; }
         // slot sl last belonged to check k-NS = k-1-D, which the host digested at the end of the previous check's
         // iteration of this loop: it is free, and its check's view is the newest one that is safe to show the sweeps
-        if (check && k >= NS) view = e->st_view + (size_t)((k - NS) % NV) * g.members;
+        const int vi = k >= NS ? (k - NS) % NV : NV - 1;
+        view = e->st_view + (size_t)vi * g.members;
         bool snapped = false;
-        if (n == 1)
-            launch_sweep(g, e->psi[cur], e->psi[cur ^ 1], e->coe, e->f, check ? resbuf[sl] : nullptr, view, alpha, s);
-        else
-            snapped = launch_blocked(e, e->psi[cur], e->psi[cur ^ 1], check ? resbuf[sl] : nullptr, alpha, n, view,
-                                     check ? snapbuf[sl] : nullptr);
-        cur ^= 1;
-        e->timing.sweep_launches += 1;
-        e->timing.iterations += n;
+        int launches = 0;
+        if (use_graphs && check && cnt % cs == 0) {
+            const int key = cur | (sl << 1) | (vi << 3);
+            BlockGraph& bg = graphs.m[key];
+            if (!bg.exec) {
+                int c2 = cur;
+                HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+                enqueue_sweeps(cnt, target, true, sl, &c2, &bg.snapped, &bg.launches);
+                const hipError_t cap = hipStreamEndCapture(s, &bg.graph);
+                if (cap != hipSuccess || hipGraphInstantiate(&bg.exec, bg.graph, nullptr, nullptr, 0) != hipSuccess)
+                    return fail(XEE_ERR_HIP, "sweep block: graph capture failed");
+            }
+            HIPCHK(hipGraphLaunch(bg.exec, s));
+            snapped = bg.snapped; launches = bg.launches;
+            cur ^= (launches & 1);
+        } else {
+            enqueue_sweeps(cnt, target, check, sl, &cur, &snapped, &launches);
+        }
+        e->timing.sweep_launches += launches;
+        e->timing.iterations += target - cnt;
+        cnt = target;
         if (check) {
             hipStream_t c = cst[ci];
             if (block_events) { HIPCHK(hipEventRecord(e->evB[sl][1], s)); block_open = false; }
-            if (!snapped) launch_copy_active(g, e->psi[cur], snapbuf[sl], view, s);   // the iterate this check belongs to
             if (wide_on_sweep_stream) {
                 // the workspace is shared between checks: check k-1 must have finished with it
                 if (k >= 1) HIPCHK(hipStreamWaitEvent(s, e->evF[(k - 1) % NS], 0));

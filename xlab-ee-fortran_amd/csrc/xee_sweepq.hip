@@ -272,8 +272,13 @@ __device__ __forceinline__ bool fast_tile(const Grid& g, const TileGeom& tg, flo
         constexpr bool TRACK_MIN = decltype(track_tag)::value; // the wave needs the running minimum of |a| (see below)
         const int par = t & 1;
         __syncthreads();
-        const float below = (w > 0) ? edge[par][0][w - 1][lane] : 0.0f;
-        const float above = (w < NW - 1) ? edge[par][1][w + 1][lane] : 0.0f;
+        // (read unconditionally from a clamped slot, then select: a conditional read is a branch, and with a branch at its
+        // head the step is no longer ONE basic block -- the compiler then hoists the first pairs' lane shifts in front of
+        // it, where they cannot fold into their multiplies any more: 4 extra moves per step)
+        const float below_raw = edge[par][0][w > 0 ? w - 1 : 0][lane];
+        const float above_raw = edge[par][1][w < NW - 1 ? w + 1 : NW - 1][lane];
+        const float below = (w > 0) ? below_raw : 0.0f;
+        const float above = (w < NW - 1) ? above_raw : 0.0f;
         auto finish = [&](int k, f2 Rv) {
             Rv = Rv - ff[k];                                           // :190
             const f2 a = ALPHA1 ? Rv : alpha2 * Rv;
