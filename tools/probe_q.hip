@@ -11,7 +11,12 @@
 #include <map>
 #include <vector>
 
-namespace xee { int record_failure(int code, const char*) { return code; } }
+namespace xee {
+int record_failure(int code, const char*) { return code; }
+// (referenced by launch_sweep_q's fallback for planes of 2 GiB and more; never called here)
+void launch_sweep_tb4(const Grid&, const float*, float*, const float*, const float*, float*, const MemberState*, float, int, bool,
+                      const SweepOpts&, SweepDesc*, hipStream_t) {}
+}
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
