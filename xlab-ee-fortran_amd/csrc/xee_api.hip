@@ -719,7 +719,8 @@ int solve_pipelined(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float 
         std::map<int, BlockGraph> m;
         ~GraphCache() { for (auto& kv : m) { if (kv.second.exec) hipGraphExecDestroy(kv.second.exec); if (kv.second.graph) hipGraphDestroy(kv.second.graph); } }
     } graphs;
-    const bool use_graphs = !wide_on_sweep_stream && tb_T > 1 && cs > tb_T && max_iter / cs >= 64;
+    // (not on the legacy default stream, which cannot be captured; any capture failure falls back to plain launches)
+    bool use_graphs = !wide_on_sweep_stream && tb_T > 1 && cs > tb_T && max_iter / cs >= 64 && s != nullptr;
     if (use_graphs && !e->redo && e->have_base && e->opts.kernel != 1 && e->opts.kernel != 2) {
         // (launch_blocked allocates the tile list on first use: not inside a capture)
         HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->redo), sizeof(int) * sweep_q_redo_ints(g)));
@@ -761,12 +762,16 @@ int solve_pipelined(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float 
             BlockGraph& bg = graphs.m[key];
             if (!bg.exec) {
                 int c2 = cur;
-                HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
-                enqueue_sweeps(cnt, target, true, sl, &c2, &bg.snapped, &bg.launches);
-                const hipError_t cap = hipStreamEndCapture(s, &bg.graph);
-                if (cap != hipSuccess || hipGraphInstantiate(&bg.exec, bg.graph, nullptr, nullptr, 0) != hipSuccess)
-                    return fail(XEE_ERR_HIP, "sweep block: graph capture failed");
+                if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess) {
+                    enqueue_sweeps(cnt, target, true, sl, &c2, &bg.snapped, &bg.launches);
+                    if (hipStreamEndCapture(s, &bg.graph) != hipSuccess || hipGraphInstantiate(&bg.exec, bg.graph, nullptr, nullptr, 0) != hipSuccess)
+                        bg.exec = nullptr;
+                }
+                if (!bg.exec) { (void)hipGetLastError(); use_graphs = false; }
             }
+        }
+        if (use_graphs && check && cnt % cs == 0) {
+            BlockGraph& bg = graphs.m[cur | (sl << 1) | (vi << 3)];
             HIPCHK(hipGraphLaunch(bg.exec, s));
             snapped = bg.snapped; launches = bg.launches;
             cur ^= (launches & 1);
