@@ -20,7 +20,7 @@ def main():
     if stats:
         shutil.copy(stats[0], dst / "final_kernel_stats.csv")
     for wl_dir in sorted((src / "pmc").glob("*")):
-        for p in ("fetch", "write", "sq1", "sq2"):
+        for p in ("fetch", "write", "sq1", "sq2", "tcc"):
             files = sorted(glob.glob(str(wl_dir / p / "**" / "*counter_collection.csv"), recursive=True))
             if not files:
                 continue

@@ -13,6 +13,7 @@ for wl in $wls; do
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $d/write -- python3 $root/tools/pmc_workload.py $wl > $d/write.log 2>&1
   rocprofv3 --kernel-trace --pmc $SQ1 --output-format csv -d $d/sq1 -- python3 $root/tools/pmc_workload.py $wl > $d/sq1.log 2>&1 || echo "sq1 failed"
   rocprofv3 --kernel-trace --pmc $SQ2 --output-format csv -d $d/sq2 -- python3 $root/tools/pmc_workload.py $wl > $d/sq2.log 2>&1 || echo "sq2 failed"
+  rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --output-format csv -d $d/tcc -- python3 $root/tools/pmc_workload.py $wl > $d/tcc.log 2>&1 || echo "tcc failed"
 done
 cd $root
 python3 tools/pmc_summarize.py $out $out/summary > $out/summary.log 2>&1 || echo "summarize failed"

@@ -6,9 +6,14 @@ profiles/traffic.json (the per-launch HBM bytes bench.py quotes as roofline.traf
 
 Layout read:  <tag>/pmc/<workload>/<pass>/**/*counter_collection.csv   pass in {fetch, write, sq1, sq2}
 HBM bytes follow MI355X_MICROARCH.md (HBM / rocprofv3 PMC sections): FETCH_SIZE and WRITE_SIZE in separate
-passes, KiB per dispatch; on gfx950 FETCH_SIZE under-reports coalesced reads by a width-dependent factor, which
-is CALIBRATED IN THE SAME RUN on two kernels of known byte count: k_negate (16 B/lane: the guide's exact 1/2) and
-k_cal_eta (4 B/lane).  The sweep's factor is the one of its load width (LOAD_WIDTH below).
+passes, KiB per dispatch.  On gfx950 FETCH_SIZE tallies every fabric read request at 64 B although full lines are
+128-B requests (the guide: "reports exactly 1/2 of the bytes of a wide coalesced streaming read -- double it"), so the
+true read bytes lie between the tally and twice the tally; how far depends on the kernel's mix of partial and
+full-line requests.  Two kernels of known byte count are measured in the same run as a check of the rule (k_negate,
+16 B/lane: the exact 1/2; k_cal_eta, 4 B/lane with unaligned neighbours: 0.73), and the sweep's read bytes are taken as
+    min(2 x tally, what its tiles can request at most)   but not below   what a pass over the planes must read at least
+(both physical bounds are computed from the grid and the tiling).  With the XCD-aware tile order of round 2 the two
+ends meet: 2 x tally = the compulsory bytes to 0.2 %, i.e. every line is fetched once, as a full line.
 """
 import csv
 import glob
@@ -53,7 +58,7 @@ def main():
         if not base.exists():
             continue
         per = {}
-        for p in ("fetch", "write", "sq1", "sq2"):
+        for p in ("fetch", "write", "sq1", "sq2", "tcc"):
             if (base / p).exists():
                 per[p] = read_pass(base / p)
         if "fetch" not in per:
@@ -77,13 +82,23 @@ def main():
         if corr is None:            # 8 B/lane: not separately calibrated, bracket between the two
             corr = 0.5 * (cal.get("x16", 0.5) + cal.get("x4", 0.735))
         fetch = mean(fv[kname]["FETCH_SIZE"])
+        # physical bounds of the sweep's read bytes per launch (T = 8, 64 x H tiles stepping by 64 - 2T, H - 2T)
+        T, H = 8, (64 if op == "BAROTROPIC" else 48)
+        planes = 4 if op == "BAROTROPIC" else 6
+        ntx, nty = -(-(nr - 1) // (64 - 2 * T)), -(-(nz - 1) // (H - 2 * T))
+        lower = planes * nr * nz * 4.0 * M                                   # every plane byte once
+        upper = ntx * nty * M * (planes * 64 * H + (1 if planes == 4 else 2) * 64) * 4.0   # every tile its whole footprint
+        read_bytes = max(min(2.0 * fetch * 1024.0, upper), lower)
+        corr = fetch * 1024.0 / read_bytes
         rec = {"workload": wl, "kernel": kname, "short": short(kname), "nr": nr, "nz": nz, "members": M, "operator": op,
                "dispatches": len(fv[kname]["FETCH_SIZE"]), **fmeta[kname],
-               "FETCH_SIZE_kib": fetch, "fetch_calibration": cal, "fetch_correction": corr, "load_width_B": width}
+               "FETCH_SIZE_kib": fetch, "fetch_calibration": cal, "fetch_correction": corr, "load_width_B": width,
+               "read_bytes": read_bytes, "read_bytes_bounds": {"tally": fetch * 1024.0, "twice_tally": 2048.0 * fetch,
+                                                                "compulsory": lower, "all_tile_footprints": upper}}
         if "write" in per and kname in per["write"][0]:
             rec["WRITE_SIZE_kib"] = mean(per["write"][0][kname]["WRITE_SIZE"])
-            rec["bytes_per_launch"] = (fetch / corr + rec["WRITE_SIZE_kib"]) * 1024.0
-        for p in ("sq1", "sq2"):
+            rec["bytes_per_launch"] = read_bytes + rec["WRITE_SIZE_kib"] * 1024.0
+        for p in ("sq1", "sq2", "tcc"):
             if p in per and kname in per[p][0]:
                 for c, xs in per[p][0][kname].items():
                     rec[c] = mean(xs)
@@ -91,7 +106,7 @@ def main():
         if "bytes_per_launch" in rec:
             entries.append({k: rec[k] for k in ("workload", "short", "kernel", "nr", "nz", "members", "operator", "FETCH_SIZE_kib",
                                                 "WRITE_SIZE_kib", "fetch_correction", "bytes_per_launch")}
-                           | {c: rec[c] for c in rec if c.startswith("SQ_")})
+                           | {c: rec[c] for c in rec if c.startswith("SQ_") or c.startswith("TCC_")})
     (dst / "pmc_summary.json").write_text(json.dumps(summary, indent=1) + "\n")
     if entries:
         tj = dst.parent / "traffic.json"

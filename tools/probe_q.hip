@@ -38,8 +38,9 @@ int main(int argc, char** argv)
         CK(hipMemcpy(f, h.data(), n * 4, hipMemcpyHostToDevice));
         CK(hipMemcpy(psi0, z.data(), n * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(psi1, z.data(), n * 4, hipMemcpyHostToDevice));
     }
-    dim3 grid((g.nx - 1 + (64 - 2 * T) - 1) / (64 - 2 * T), (g.ny - 1 + (H - 2 * T) - 1) / (H - 2 * T), M);
-    const size_t nwg = (size_t)grid.x * grid.y * grid.z;
+    const int ntx = (g.nx - 1 + (64 - 2 * T) - 1) / (64 - 2 * T), nty = (g.ny - 1 + (H - 2 * T) - 1) / (H - 2 * T);
+    const size_t nwg = (size_t)ntx * nty * M;
+    const dim3 grid((unsigned)(8 * ((nwg + 7) / 8)));
     unsigned long long* stamps;
     CK(hipMalloc((void**)&stamps, nwg * 32 * 8)); CK(hipMemset(stamps, 0, nwg * 32 * 8));
     int* redo; CK(hipMalloc((void**)&redo, 4096)); CK(hipMemset(redo, 0, 4096));
@@ -47,13 +48,13 @@ int main(int argc, char** argv)
     for (int k = 0; k < 24; ++k) {
         if (k == 4) CK(hipEventRecord(e0, 0));
         hipLaunchKernelGGL((k_sweep_q<NW, R, false, true, true, false>), grid, dim3(NW * 64), 0, 0, g, (k & 1) ? psi1 : psi0, (k & 1) ? psi0 : psi1,
-                           base, f, (float*)nullptr, (float*)nullptr, (const MemberState*)nullptr, 1.0f, T, 0, redo, (unsigned long long*)nullptr);
+                           base, f, (float*)nullptr, (float*)nullptr, (const MemberState*)nullptr, 1.0f, T, 0, redo, (unsigned long long*)nullptr, ntx, nty);
     }
     CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
     float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
     const double plain_us = ms * 1e3 / 20.0;
     hipLaunchKernelGGL((k_sweep_q<NW, R, false, true, true, true>), grid, dim3(NW * 64), 0, 0, g, psi0, psi1, base, f, (float*)nullptr, (float*)nullptr,
-                       (const MemberState*)nullptr, 1.0f, T, 0, redo, stamps);
+                       (const MemberState*)nullptr, 1.0f, T, 0, redo, stamps, ntx, nty);
     CK(hipDeviceSynchronize());
     std::vector<unsigned long long> st(nwg * 32);
     CK(hipMemcpy(st.data(), stamps, nwg * 32 * 8, hipMemcpyDeviceToHost));

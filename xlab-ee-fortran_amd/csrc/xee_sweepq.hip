@@ -579,15 +579,23 @@ template <int NW, int R, bool WRITE_R, bool BARO, bool ALPHA1, bool STAMP = fals
 __global__ __launch_bounds__(NW * 64, (BARO || NW * R < 64) ? 4 : 1) void k_sweep_q(Grid g, const float* __restrict__ psi_in,
         float* __restrict__ psi_out, const float* __restrict__ base, const float* __restrict__ f,
         float* __restrict__ res, float* __restrict__ snap, const MemberState* __restrict__ st, float alpha, int T, int exact_only,
-        int* __restrict__ redo, unsigned long long* __restrict__ stamps)
+        int* __restrict__ redo, unsigned long long* __restrict__ stamps, int ntx, int nty)
 {
     __shared__ float edge[2][2][NW][64];
     __shared__ int vote[NW];
-    const int m = blockIdx.z;
+    // XCD-aware tile order.  The grid is one-dimensional; the dispatcher deals workgroups to the eight XCDs round-robin
+    // (workgroup b runs on XCD b % 8), each with its own L2.  The tile list (column, row, member order) is cut into eight
+    // contiguous parts and XCD x walks part x, so the tiles in flight on one L2 at a time are neighbours whose halos
+    // overlap: the overlap is then read from HBM once instead of once per XCD that touches it.
+    const int ntile = ntx * nty * g.members;
+    const int part = (ntile + 7) >> 3;
+    const int tile = ((int)blockIdx.x & 7) * part + ((int)blockIdx.x >> 3);
+    if (tile >= ntile) return;                            // (the grid is padded to a multiple of eight)
+    const int m = tile / (ntx * nty);
     const MemberState* member = st ? st + m : nullptr;
-    TileGeom tg = make_geom<NW, R>(g, T, (int)blockIdx.x, (int)blockIdx.y, m);
+    TileGeom tg = make_geom<NW, R>(g, T, tile % ntx, (tile / ntx) % nty, m);
     if constexpr (STAMP) {
-        tg.stamps = stamps + 32 * ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+        tg.stamps = stamps + 32 * (size_t)tile;
         stamp<STAMP>(tg, 0);                              // workgroup started
         if (threadIdx.x == 0)                             // HW_ID (cu/sh/se in bits 8..15) and XCC_ID
             tg.stamps[7] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |
@@ -605,7 +613,7 @@ __global__ __launch_bounds__(NW * 64, (BARO || NW * R < 64) ? 4 : 1) void k_swee
     if constexpr (WRITE_R) {
         if (threadIdx.x == 0) {
             const int slot = atomicAdd(redo, 1);
-            redo[1 + slot] = (int)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+            redo[1 + slot] = tile;                         // = (member * nty + row) * ntx + column
         }
     } else {
         exact_tile<NW, R, WRITE_R, BARO>(g, tg, edge, psi_in, psi_out, base, f, res, snap, alpha, T, member);
@@ -698,13 +706,15 @@ static void launch_q_cfg(const Grid& g, const float* psi_in, float* psi_out, con
                          float* res, float* snap, const MemberState* st, float alpha, int T, int exact_only, int* redo, hipStream_t s)
 {
     constexpr int H = NW * R;
-    dim3 grid((g.nx - 1 + (64 - 2 * T) - 1) / (64 - 2 * T), (g.ny - 1 + (H - 2 * T) - 1) / (H - 2 * T), g.members);
+    const int ntx = (g.nx - 1 + (64 - 2 * T) - 1) / (64 - 2 * T), nty = (g.ny - 1 + (H - 2 * T) - 1) / (H - 2 * T);
+    const long long ntile = (long long)ntx * nty * g.members;
+    const dim3 grid((unsigned)(8 * ((ntile + 7) / 8)));    // one-dimensional, a multiple of eight: see the kernel's tile order
     const bool a1 = alpha == 1.0f;     // the protocol's damping: 1.0f * x is x, the multiply is not issued
-#define Q_LAUNCH(WR, A1) hipLaunchKernelGGL((k_sweep_q<NW, R, WR, BARO, A1>), grid, dim3(NW * 64), 0, s, g, psi_in, psi_out, base, f, res, snap, st, alpha, T, exact_only, redo, (unsigned long long*)nullptr)
+#define Q_LAUNCH(WR, A1) hipLaunchKernelGGL((k_sweep_q<NW, R, WR, BARO, A1>), grid, dim3(NW * 64), 0, s, g, psi_in, psi_out, base, f, res, snap, st, alpha, T, exact_only, redo, (unsigned long long*)nullptr, ntx, nty)
     if (res) {                         // (redo[0] is zero here: zeroed at allocation, and by every k_sweep_q_redo when it ends)
         if (a1) Q_LAUNCH(true, true); else Q_LAUNCH(true, false);
         hipLaunchKernelGGL((k_sweep_q_redo<NW, R, BARO>), dim3(exact_only ? 1024 : 64), dim3(NW * 64), 0, s, g, psi_in, psi_out, base, f, res, snap, st,
-                           alpha, T, redo, (int)grid.x, (int)grid.y, (int)sweep_q_redo_ints(g) - 2);
+                           alpha, T, redo, ntx, nty, (int)sweep_q_redo_ints(g) - 2);
     }
     else { if (a1) Q_LAUNCH(false, true); else Q_LAUNCH(false, false); }
 #undef Q_LAUNCH
