@@ -275,10 +275,18 @@ __device__ __forceinline__ bool fast_tile(const Grid& g, const TileGeom& tg, flo
         // (read unconditionally from a clamped slot, then select: a conditional read is a branch, and with a branch at its
         // head the step is no longer ONE basic block -- the compiler then hoists the first pairs' lane shifts in front of
         // it, where they cannot fold into their multiplies any more: 4 extra moves per step)
-        const float below_raw = edge[par][0][w > 0 ? w - 1 : 0][lane];
-        const float above_raw = edge[par][1][w < NW - 1 ? w + 1 : NW - 1][lane];
-        const float below = (w > 0) ? below_raw : 0.0f;
-        const float above = (w < NW - 1) ? above_raw : 0.0f;
+        // (the nine-weight body shifts with separate moves anyway, and the two extra live values made it spill: it keeps
+        // the conditional reads)
+        float below, above;
+        if constexpr (BARO) {
+            const float below_raw = edge[par][0][w > 0 ? w - 1 : 0][lane];
+            const float above_raw = edge[par][1][w < NW - 1 ? w + 1 : NW - 1][lane];
+            below = (w > 0) ? below_raw : 0.0f;
+            above = (w < NW - 1) ? above_raw : 0.0f;
+        } else {
+            below = (w > 0) ? edge[par][0][w - 1][lane] : 0.0f;
+            above = (w < NW - 1) ? edge[par][1][w + 1][lane] : 0.0f;
+        }
         auto finish = [&](int k, f2 Rv) {
             Rv = Rv - ff[k];                                           // :190
             const f2 a = ALPHA1 ? Rv : alpha2 * Rv;
@@ -360,6 +368,16 @@ __device__ __forceinline__ bool fast_tile(const Grid& g, const TileGeom& tg, flo
             if (in_q) step(p, q, t, std::true_type{}, TRACK);                                                      \
             else { step(p, q, t, std::false_type{}, TRACK); step(q, p, t + 1, std::true_type{}, TRACK); }          \
         } else {                                                                                                   \
+            /* (four steps per trip for the star: the compiler's copies at the loop's back edge are paid half as   \
+               often, 178 instead of 186 VALU instructions per two steps; the nine-weight body would spill) */     \
+            if constexpr (BARO) {                                                                                  \
+                for (; t + 3 < T; t += 4) {                                                                        \
+                    step(p, q, t, std::false_type{}, TRACK);                                                       \
+                    step(q, p, t + 1, std::false_type{}, TRACK);                                                   \
+                    step(p, q, t + 2, std::false_type{}, TRACK);                                                   \
+                    step(q, p, t + 3, std::false_type{}, TRACK);                                                   \
+                }                                                                                                  \
+            }                                                                                                      \
             for (; t + 1 < T; t += 2) {                                                                            \
                 step(p, q, t, std::false_type{}, TRACK);                                                           \
                 step(q, p, t + 1, std::false_type{}, TRACK);                                                       \
