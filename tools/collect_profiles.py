@@ -16,12 +16,12 @@ KEEP = ("k_sweep", "k_negate", "k_cal_eta")
 def main():
     src, dst = Path(sys.argv[1]), Path(sys.argv[2])
     (dst / "pmc").mkdir(parents=True, exist_ok=True)
-    stats = sorted(glob.glob(str(src / "stats" / "**" / "*kernel_stats.csv"), recursive=True))
-    if stats:
-        shutil.copy(stats[0], dst / "final_kernel_stats.csv")
+    newest = lambda pattern: sorted(glob.glob(pattern, recursive=True), key=lambda f: Path(f).stat().st_mtime)[-1:]
+    for f in newest(str(src / "stats" / "**" / "*kernel_stats.csv")):
+        shutil.copy(f, dst / "final_kernel_stats.csv")
     for wl_dir in sorted((src / "pmc").glob("*")):
         for p in ("fetch", "write", "sq1", "sq2", "tcc"):
-            files = sorted(glob.glob(str(wl_dir / p / "**" / "*counter_collection.csv"), recursive=True))
+            files = newest(str(wl_dir / p / "**" / "*counter_collection.csv"))
             if not files:
                 continue
             rows = list(csv.DictReader(open(files[0])))

@@ -32,13 +32,23 @@ def read_pass(d):
     """-> {kernel_name: {counter: [values per dispatch]}}, {kernel_name: meta}"""
     vals = defaultdict(lambda: defaultdict(list))
     meta = {}
-    for fn in glob.glob(str(d / "**" / "*counter_collection.csv"), recursive=True):
+    files = sorted(glob.glob(str(d / "**" / "*counter_collection.csv"), recursive=True), key=lambda f: Path(f).stat().st_mtime)
+    rows_of = defaultdict(list)
+    for fn in files[-1:]:                                  # (the newest run only, should the directory hold several)
         with open(fn, newline="") as f:
             for row in csv.DictReader(f):
-                k = row["Kernel_Name"]
-                vals[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
-                meta[k] = {"grid": int(row["Grid_Size"]), "wg": int(row["Workgroup_Size"]), "vgpr": int(row["VGPR_Count"]),
-                           "agpr": int(row["Accum_VGPR_Count"]), "lds": int(row["LDS_Block_Size"]), "scratch": int(row["Scratch_Size"])}
+                rows_of[row["Kernel_Name"]].append(row)
+    for k, rows in rows_of.items():
+        # a kernel's dispatches of its most frequent grid only: the sweep's short launch at the head of a block has fewer,
+        # larger tiles and would blur the per-launch means
+        grids = [int(r["Grid_Size"]) for r in rows]
+        mode = max(set(grids), key=grids.count)
+        for row in rows:
+            if int(row["Grid_Size"]) != mode:
+                continue
+            vals[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+            meta[k] = {"grid": int(row["Grid_Size"]), "wg": int(row["Workgroup_Size"]), "vgpr": int(row["VGPR_Count"]),
+                       "agpr": int(row["Accum_VGPR_Count"]), "lds": int(row["LDS_Block_Size"]), "scratch": int(row["Scratch_Size"])}
     return vals, meta
 
 
