@@ -368,16 +368,6 @@ __device__ __forceinline__ bool fast_tile(const Grid& g, const TileGeom& tg, flo
             if (in_q) step(p, q, t, std::true_type{}, TRACK);                                                      \
             else { step(p, q, t, std::false_type{}, TRACK); step(q, p, t + 1, std::true_type{}, TRACK); }          \
         } else {                                                                                                   \
-            /* (four steps per trip for the star: the compiler's copies at the loop's back edge are paid half as   \
-               often, 178 instead of 186 VALU instructions per two steps; the nine-weight body would spill) */     \
-            if constexpr (BARO) {                                                                                  \
-                for (; t + 3 < T; t += 4) {                                                                        \
-                    step(p, q, t, std::false_type{}, TRACK);                                                       \
-                    step(q, p, t + 1, std::false_type{}, TRACK);                                                   \
-                    step(p, q, t + 2, std::false_type{}, TRACK);                                                   \
-                    step(q, p, t + 3, std::false_type{}, TRACK);                                                   \
-                }                                                                                                  \
-            }                                                                                                      \
             for (; t + 1 < T; t += 2) {                                                                            \
                 step(p, q, t, std::false_type{}, TRACK);                                                           \
                 step(q, p, t + 1, std::false_type{}, TRACK);                                                       \
