@@ -72,24 +72,35 @@ __device__ __forceinline__ ExactSum chunk_summary(const ChunkAddr& a, int pitch,
 {
     unsigned ke = 0, ko = 0;
     bool ok = true;
-    for (int r = 0; r < a.n; ++r) {
-        const float x = a.p[(size_t)r * pitch];
+    // (all of the chunk's terms are requested before the first one is looked at: a load per trip of the loop below made
+    // the kernel wait for memory 32 times in a row)
+    float xs[SEG];
+#pragma unroll
+    for (int r = 0; r < SEG; ++r) xs[r] = (r < a.n) ? a.p[(size_t)r * pitch] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < SEG; ++r) {
+        // (no break / continue: the loop must unroll for xs[] to stay in registers; `ok` going false ends the work)
+        const float x = xs[r];
         const unsigned tb = f2u(x * x);                      // to_dat(i,j)**2.0, >= +0
         const unsigned Et = (tb >> 23) & 0xffu;
         const unsigned fr = tb & 0x7fffffu;
-        if (Et == 255u) { ok = false; break; }               // Inf / NaN term: genuine adds only
         const unsigned Mt = Et ? (fr | 0x800000u) : fr;
-        if (Mt == 0u) continue;                              // + 0
         const int shift = eu - ((int)(Et ? Et : 1u) - 150);
-        if (shift <= 0) { ok = false; break; }               // term >= 2^23 ulps: leaves the binade
-        if (shift >= 25) continue;                           // < half an ulp: absorbed
-        const unsigned q = Mt >> shift;
-        const unsigned rem = Mt & ((1u << shift) - 1u);
-        const unsigned half = 1u << (shift - 1);
-        const unsigned up_e = (rem > half) || (rem == half && ((ke + q) & 1u));
-        const unsigned up_o = (rem > half) || (rem == half && (((ko + q) & 1u) ^ 1u));
-        ke += q + up_e;
-        ko += q + up_o;
+        if (r < a.n && ok) {
+            if (Et == 255u) ok = false;                      // Inf / NaN term: genuine adds only
+            else if (Mt != 0u) {                             // (+0 adds nothing)
+                if (shift <= 0) ok = false;                  // term >= 2^23 ulps: leaves the binade
+                else if (shift < 25) {                       // (>= 25: below half an ulp, absorbed)
+                    const unsigned q = Mt >> shift;
+                    const unsigned rem = Mt & ((1u << shift) - 1u);
+                    const unsigned half = 1u << (shift - 1);
+                    const unsigned up_e = (rem > half) || (rem == half && ((ke + q) & 1u));
+                    const unsigned up_o = (rem > half) || (rem == half && (((ko + q) & 1u) ^ 1u));
+                    ke += q + up_e;
+                    ko += q + up_o;
+                }
+            }
+        }
     }
     ExactSum out;
     out.eu = eu;
@@ -125,11 +136,15 @@ __global__ __launch_bounds__(256) void k_ex_chunk_sums(Grid g, const float* __re
     const int seg = blockIdx.y * 4 + threadIdx.y;
     if (col >= ncol || seg >= nseg) return;
     const ChunkAddr a = chunk_addr(g, R + (size_t)m * g.plane, col, seg, nrows);
+    // (the loads first, all of them in flight together; then the sum in the reference's order)
+    float xs[SEG];
+#pragma unroll
+    for (int r = 0; r < SEG; ++r) xs[r] = (r < a.n) ? a.p[(size_t)r * g.pitch] : 0.0f;
     double acc = 0.0;
-    for (int r = 0; r < a.n; ++r) {
-        const float x = a.p[(size_t)r * g.pitch];
-        const float t = x * x;
-        acc += (double)t;
+#pragma unroll
+    for (int r = 0; r < SEG; ++r) {
+        const float t = xs[r] * xs[r];
+        if (r < a.n) acc += (double)t;
     }
     sigma[(size_t)m * ncol * nseg + (size_t)col * nseg + seg] = acc;
 }
