@@ -658,7 +658,7 @@ int solve_pipelined(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float 
         HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->ex_slow2), sizeof(int) * g.members));
     }
     // Views.  Check j's state machine writes view j % NV.  The sweeps start on view NV-1 (a copy of the initial states)
-    // and, at the residual-writing launch of check k, move to the view of check k-1-D: the newest check the host has
+    // and, at the head of the block that ends in check k, move to the view of check k-1-D: the newest check the host has
     // digested, so it is complete and no stream wait is needed.  Until the next move that view is only read: the state
     // machines that may run meanwhile are those of checks k-D .. k, which write other views (NV = 4 > D + 1).
     // (a stale view only costs work: a member found stopped keeps iterating until the sweeps see it and its result is
