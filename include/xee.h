@@ -99,6 +99,13 @@ int xee_solve_elliptic(int *max_iter, int check_step, int converge_time, int los
  * kernel (k_sweep_tb).  Same results either way. */
 int xee_last_sweep_info(char *name, int name_len, int *T, int *tile_w, int *tile_h);
 
+/* The Tier-1 entry points work through a one-member device ensemble that is KEPT per calling thread and reused while the
+ * grid (nx, ny) and the device stay the same -- a reused one is put back into the state of a fresh one first (planes
+ * zero-filled, options from the process defaults).  It holds device memory for about forty planes of the last grid, plus
+ * the copy of this thread's last xee_cal_coe; this call frees both (the next Tier-1 call simply builds them again).
+ * A call that fails drops the cached ensemble by itself. */
+int xee_tier1_release(void);
+
 /* replaces the residual norm inside solve_elliptic, elliptic_tools.f90:193-199, as a stand-alone call:
  * *sum_sq = the sequential fp32 sum (i outer, j inner) of res(i,j)**2 over the interior, bit for bit;
  * *rms = sqrt(sum_sq / ((nx-2)*(ny-2))).  slow_chunks (may be NULL) reports how many 32-term chunks the

@@ -18,10 +18,12 @@ using namespace xee;
 namespace {
 
 thread_local std::string g_err;
+thread_local unsigned long long g_failures = 0;     // how many errors this thread has reported (see Tier1 below)
 
 int fail(int code, const std::string& msg)
 {
     g_err = msg;
+    ++g_failures;
     return code;
 }
 
@@ -1211,11 +1213,77 @@ int xee_ensemble_time_sweeps(xee_ensemble_t* e, int iters, int variant, float al
 // ---------------------------------------------------------------------------------------------
 
 namespace {
-struct Scoped {
+// The one-member ensemble behind the Tier-1 entry points is KEPT per thread and reused while the grid stays the same:
+// creating and destroying one costs ~15 ms (thirty allocations, pinned host memory, streams, events, their release)
+// against 1-3 ms of work for a small solve -- the reference program and the legacy program make dozens of such calls.
+// A reused ensemble is put back into the state of a fresh one: every plane it holds zero-filled, flags and options reset
+// (process defaults are read again).  A call that reports an error drops the cached ensemble; xee_tier1_release() frees
+// it explicitly (it holds device memory: about forty planes of the last grid).
+struct Tier1Cache { xee_ensemble_t* e = nullptr; int nx = 0, ny = 0; };
+thread_local Tier1Cache g_t1;
+
+void tier1_drop()
+{
+    if (g_t1.e) xee_ensemble_destroy(g_t1.e);
+    g_t1 = Tier1Cache{};
+}
+
+int tier1_reset(xee_ensemble* e)
+{
+    HIPCHK(hipSetDevice(e->device));
+    hipStream_t s = e->stream;
+    const size_t pb = e->g.plane * e->g.members * sizeof(float);
+    for (float* p : {e->A, e->B, e->C, e->bc, e->f, e->psi[0], e->psi[1], e->sA, e->sB, e->sC, e->res, e->eta, e->u, e->w,
+                     e->Q, e->terms, e->res2, e->res3})
+        if (p) HIPCHK(hipMemsetAsync(p, 0, pb, s));
+    if (e->coe) HIPCHK(hipMemsetAsync(e->coe, 0, 9 * pb, s));
+    if (e->base) HIPCHK(hipMemsetAsync(e->base, 0, 4 * pb, s));
+    if (e->snap) HIPCHK(hipMemsetAsync(e->snap, 0, 3 * pb, s));
+    const size_t nv = (size_t)(e->g.nx > e->g.ny ? e->g.nx : e->g.ny) + 64;
+    for (float* v : {e->ra, e->za, e->rcuva, e->rho, e->exner})
+        if (v) HIPCHK(hipMemsetAsync(v, 0, nv * sizeof(float), s));
+    if (e->redo) HIPCHK(hipMemsetAsync(e->redo, 0, sizeof(int) * sweep_q_redo_ints(e->g), s));
+    e->opts = g_defaults.sweep;
+    e->sync_checks = g_defaults.sync_checks != 0;
+    e->exact_serial = g_defaults.exact_sum_serial != 0;
+    e->have_profiles = false;
+    e->have_base = false;
+    e->base_baro = false;
+    e->uv = UniformVals{};
+    e->dr = e->dz = 0.f;
+    e->cur = 0;
+    e->first_case_id = 0;
+    e->timing = xee_timing_t{};
+    e->last_sweep = SweepDesc{};
+    e->sx_slow.clear();
+    e->rec.assign(e->g.members, xee_case_record_t{});
+    for (int m = 0; m < e->g.members; ++m) e->rec[m].case_id = m;
+    launch_state_init(e->g, e->st, s);
+    return XEE_OK;
+}
+
+struct Tier1 {
     xee_ensemble_t* e = nullptr;
-    ~Scoped() { if (e) xee_ensemble_destroy(e); }
+    unsigned long long failures0 = 0;
+    int acquire(int nx, int ny)
+    {
+        failures0 = g_failures;
+        int dev = 0;
+        if (g_t1.e && (g_t1.nx != nx || g_t1.ny != ny || hipGetDevice(&dev) != hipSuccess || dev != g_t1.e->device)) tier1_drop();
+        if (g_t1.e) {
+            const int st = tier1_reset(g_t1.e);
+            if (st != XEE_OK) { tier1_drop(); return st; }
+        } else {
+            XCHK(xee_ensemble_create(&g_t1.e, nx, ny, 1, -1));
+            g_t1.nx = nx; g_t1.ny = ny;
+        }
+        e = g_t1.e;
+        return XEE_OK;
+    }
+    ~Tier1() { if (e && g_failures != failures0) tier1_drop(); }   // (whatever went wrong, the next call starts afresh)
 };
 }  // namespace
+
 
 namespace {
 // What the last xee_cal_coe of this thread produced, kept on the device: the solver coefficients it was given and the
@@ -1233,6 +1301,14 @@ struct CoeCache {
 };
 thread_local CoeCache g_cc;
 thread_local SweepDesc g_last_tier1_sweep{};
+
+void tier1_release_all()
+{
+    tier1_drop();
+    if (g_cc.abc) hipFree(g_cc.abc);
+    if (g_cc.coe) hipFree(g_cc.coe);
+    g_cc.abc = g_cc.coe = nullptr; g_cc.plane = 0; g_cc.device = -1; g_cc.valid = false;
+}
 
 int cache_store(xee_ensemble* e, const float* b_host, float dx, float dy)
 {
@@ -1289,6 +1365,12 @@ int cache_try(xee_ensemble* e)
 }
 }  // namespace
 
+int xee_tier1_release(void)
+{
+    tier1_release_all();
+    return XEE_OK;
+}
+
 int xee_last_sweep_info(char* name, int name_len, int* T, int* tile_w, int* tile_h)
 {
     if (name && name_len > 0) { strncpy(name, g_last_tier1_sweep.name, (size_t)name_len - 1); name[name_len - 1] = 0; }
@@ -1302,8 +1384,8 @@ int xee_cal_coe(const float* a, const float* b, const float* c, float* coe, floa
 {
     if (!a || !b || !c || !coe || !err) return fail(XEE_ERR_INVALID_ARGUMENT, "null argument");
     *err = 1;                                                   // elliptic_tools.f90:33
-    Scoped sc;
-    XCHK(xee_ensemble_create(&sc.e, nx, ny, 1, -1));
+    Tier1 sc;
+    XCHK(sc.acquire(nx, ny));
     xee_ensemble_t* e = sc.e;
     XCHK(xee_ensemble_upload(e, XEE_F_SOLVER_A, 0, 1, a));
     XCHK(xee_ensemble_upload(e, XEE_F_SOLVER_B, 0, 1, b));
@@ -1340,8 +1422,8 @@ static int upload_coe_aos(xee_ensemble_t* e, const float* coe)
 int xee_do_elliptic(const float* psi, const float* coe, float* outdat, int nx, int ny, int* err)
 {
     if (!psi || !coe || !outdat || !err) return fail(XEE_ERR_INVALID_ARGUMENT, "null argument");
-    Scoped sc;
-    XCHK(xee_ensemble_create(&sc.e, nx, ny, 1, -1));
+    Tier1 sc;
+    XCHK(sc.acquire(nx, ny));
     xee_ensemble_t* e = sc.e;
     XCHK(upload_coe_aos(e, coe));
     XCHK(xee_ensemble_upload(e, XEE_F_BC_INIT, 0, 1, psi));
@@ -1379,8 +1461,8 @@ int xee_solve_elliptic(int* max_iter, int check_step, int converge_time, int los
         printf("   converge time :  %d\n", converge_time > 0 ? converge_time : 10);
         printf(" ---------------------------------\n");
     }
-    Scoped sc;
-    XCHK(xee_ensemble_create(&sc.e, nx, ny, 1, -1));
+    Tier1 sc;
+    XCHK(sc.acquire(nx, ny));
     xee_ensemble_t* e = sc.e;
     XCHK(upload_coe_aos(e, coe));
     XCHK(cache_try(e));                                         // this thread's last cal_coe made exactly this coe?
@@ -1404,8 +1486,8 @@ int xee_solve_elliptic(int* max_iter, int check_step, int converge_time, int los
 int xee_residual_norm(const float* res, int nx, int ny, float* sum_sq, float* rms, int* slow_chunks)
 {
     if (!res || !sum_sq || !rms) return fail(XEE_ERR_INVALID_ARGUMENT, "null argument");
-    Scoped sc;
-    XCHK(xee_ensemble_create(&sc.e, nx, ny, 1, -1));
+    Tier1 sc;
+    XCHK(sc.acquire(nx, ny));
     xee_ensemble_t* e = sc.e;
     XCHK(xee_ensemble_upload(e, XEE_F_RESIDUAL, 0, 1, res));
     if (e->exact_serial) launch_seqsum(e->g, e->res, 1, nx - 1, 1, ny - 1, true, e->sums, nullptr, e->stream);
@@ -1426,8 +1508,8 @@ int xee_solver_coefficients(const float* rhoA, const float* rhoB, const float* r
 {
     if (!rhoA || !rhoB || !rhoC || !rcuva || !rho || !solverA || !solverB || !solverC)
         return fail(XEE_ERR_INVALID_ARGUMENT, "null argument");
-    Scoped sc;
-    XCHK(xee_ensemble_create(&sc.e, nr, nz, 1, -1));
+    Tier1 sc;
+    XCHK(sc.acquire(nr, nz));
     xee_ensemble_t* e = sc.e;
     std::vector<float> zr(nr, 0.f), zz(nz, 0.f);
     XCHK(xee_ensemble_set_profiles(e, zr.data(), zz.data(), rcuva, rho, zz.data(), 0.f, 0.f));
@@ -1449,8 +1531,8 @@ int xee_cal_eta(const float* rchi, float* eta, const float* ra, const float* rcu
                 const float* exner, int nr, int nz)
 {
     if (!rchi || !eta || !ra || !rcuva || !rho || !exner) return fail(XEE_ERR_INVALID_ARGUMENT, "null argument");
-    Scoped sc;
-    XCHK(xee_ensemble_create(&sc.e, nr, nz, 1, -1));
+    Tier1 sc;
+    XCHK(sc.acquire(nr, nz));
     xee_ensemble_t* e = sc.e;
     std::vector<float> zz(nz, 0.f);
     XCHK(xee_ensemble_set_profiles(e, ra, zz.data(), rcuva, rho, exner, 0.f, 0.f));
@@ -1463,8 +1545,8 @@ int xee_cal_uw(const float* rpsi, float* u, float* w, const float* ra, const flo
                const float* rho, int nr, int nz)
 {
     if (!rpsi || !u || !w || !ra || !za || !rcuva || !rho) return fail(XEE_ERR_INVALID_ARGUMENT, "null argument");
-    Scoped sc;
-    XCHK(xee_ensemble_create(&sc.e, nr, nz, 1, -1));
+    Tier1 sc;
+    XCHK(sc.acquire(nr, nz));
     xee_ensemble_t* e = sc.e;
     XCHK(xee_ensemble_set_profiles(e, ra, za, rcuva, rho, rho, 0.f, 0.f));
     XCHK(xee_ensemble_upload(e, XEE_F_PSI, 0, 1, rpsi));
@@ -1477,8 +1559,8 @@ static int integrate_common(const float* wgt, const float* eta, const float* ra,
                             const float* rcuva, const float* rho, int nr, int nz, float* sum)
 {
     if (!wgt || !ra || !za || !rcuva || !rho || !sum) return fail(XEE_ERR_INVALID_ARGUMENT, "null argument");
-    Scoped sc;
-    XCHK(xee_ensemble_create(&sc.e, nr, nz, 1, -1));
+    Tier1 sc;
+    XCHK(sc.acquire(nr, nz));
     xee_ensemble_t* e = sc.e;
     XCHK(xee_ensemble_set_profiles(e, ra, za, rcuva, rho, rho, 0.f, 0.f));
     XCHK(xee_ensemble_upload(e, XEE_F_Q, 0, 1, wgt));
@@ -1513,8 +1595,8 @@ int xee_cal_sum_Qeta(const float* Q, const float* eta, const float* ra, const fl
 int xee_cal_wtheta(const float* w_A, const float* theta_B, float* wtheta_B, int nr, int nz)
 {
     if (!w_A || !theta_B || !wtheta_B) return fail(XEE_ERR_INVALID_ARGUMENT, "null argument");
-    Scoped sc;
-    XCHK(xee_ensemble_create(&sc.e, nr, nz, 1, -1));
+    Tier1 sc;
+    XCHK(sc.acquire(nr, nz));
     xee_ensemble_t* e = sc.e;
     XCHK(xee_ensemble_upload(e, XEE_F_W, 0, 1, w_A));
     XCHK(xee_ensemble_upload(e, XEE_F_Q, 0, 1, theta_B));
@@ -1531,8 +1613,8 @@ int xee_cal_wtheta(const float* w_A, const float* theta_B, float* wtheta_B, int 
 int xee_rhs_thermal(const float* Q_B, const float* ra, const float* exner, float* rhs_O, int nr, int nz)
 {
     if (!Q_B || !ra || !exner || !rhs_O) return fail(XEE_ERR_INVALID_ARGUMENT, "null argument");
-    Scoped sc;
-    XCHK(xee_ensemble_create(&sc.e, nr, nz, 1, -1));
+    Tier1 sc;
+    XCHK(sc.acquire(nr, nz));
     xee_ensemble_t* e = sc.e;
     std::vector<float> zz(nz, 0.f);
     XCHK(xee_ensemble_set_profiles(e, ra, zz.data(), ra, zz.data(), exner, 0.f, 0.f));
@@ -1546,8 +1628,8 @@ int xee_rhs_thermal(const float* Q_B, const float* ra, const float* exner, float
 int xee_rhs_from_B(const float* b_B, float* f_O, int nr, int nz)
 {
     if (!b_B || !f_O) return fail(XEE_ERR_INVALID_ARGUMENT, "null argument");
-    Scoped sc;
-    XCHK(xee_ensemble_create(&sc.e, nr, nz, 1, -1));
+    Tier1 sc;
+    XCHK(sc.acquire(nr, nz));
     xee_ensemble_t* e = sc.e;
     XCHK(xee_ensemble_upload(e, XEE_F_Q, 0, 1, b_B));
     launch_rhs_from_B(e->g, e->Q, e->f, e->stream);

@@ -303,6 +303,11 @@ interface
         integer(c_int), value :: nr, nz
         integer(c_int) :: st
     end function
+    ! frees the device ensemble the Tier-1 calls of this thread keep between calls (include/xee.h)
+    function xee_tier1_release() bind(C, name="xee_tier1_release") result(st)
+        import :: c_int
+        integer(c_int) :: st
+    end function
 end interface
 
 contains

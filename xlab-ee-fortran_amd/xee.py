@@ -13,7 +13,7 @@ import numpy as np
 
 _HERE = Path(__file__).resolve().parent
 
-__all__ = ["Ensemble", "Comm", "comm_unique_id", "COMM_ID_BYTES", "XeeError", "lib", "lib_path", "device_count", "set_default_option", "reset_default_options", "last_sweep_info",
+__all__ = ["Ensemble", "Comm", "comm_unique_id", "COMM_ID_BYTES", "XeeError", "lib", "lib_path", "device_count", "set_default_option", "reset_default_options", "last_sweep_info", "tier1_release",
            "profiles", "cal_coe", "do_elliptic", "solve_elliptic", "solver_coefficients", "residual_norm", "cal_eta", "cal_uw",
            "integrate_weight_B", "cal_sum_Qeta", "cal_wtheta", "rhs_thermal", "rhs_from_B", "rhs_momentum", "fd_stencil",
            "exchange_conversion", "legacy_averages", "JJ_B", "add_fields", "diagnose_case", "CaseRecord", "RECORD_DTYPE", "Timing", "FIELDS", "FD_STENCILS",
@@ -160,6 +160,11 @@ def last_sweep_info():
     _chk(lib().xee_last_sweep_info(buf, 64, C.byref(T), C.byref(tw), C.byref(th)))
     name = buf.value.decode()
     return {"name": name, "kernel": name.split("<")[0], "T": T.value, "tile": f"{tw.value}x{th.value}"}
+
+
+def tier1_release():
+    """Free this thread's cached Tier-1 ensemble and cal_coe copy (xee_tier1_release)."""
+    _chk(lib().xee_tier1_release())
 
 
 def set_default_option(key, value):
