@@ -186,16 +186,22 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--members", type=int, default=32, help="cases per GPU (weak scaling)")
+    ap.add_argument("--members", type=int, default=None, help="cases per GPU (weak scaling; default 32), timesteps per GPU for "
+                                                              "--workload sweep (default 8: 48 cases)")
     ap.add_argument("--nr", type=int, default=1024)
     ap.add_argument("--nz", type=int, default=512)
     ap.add_argument("--max-iter", type=int, default=100000)
     ap.add_argument("--cpu-sample-iters", type=int, default=500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="ensemble", choices=["ensemble", "single", "highres", "baroclinic"],
+    ap.add_argument("--workload", default="ensemble", choices=["ensemble", "single", "highres", "baroclinic", "sweep"],
                     help="ensemble (default: the bench line) | single (configs[1]: one case) | highres (configs[3]: one "
-                         "4096x2048 case, 2,000 iterations) | baroclinic (the ensemble with the full-B operator)")
+                         "4096x2048 case, 2,000 iterations) | baroclinic (the ensemble with the full-B operator) | sweep "
+                         "(configs[4]: per timestep {L(B=0), L(B)} x {-B, thermal, zero RHS with a rim boundary})")
+    ap.add_argument("--sweep-split", action="store_true", help="--workload sweep: six (operator, kind) stages one after the "
+                    "other instead of one fused batch per operator -- slower, but per_stage then separates the kinds")
     args = ap.parse_args()
+    if args.members is None:
+        args.members = 8 if args.workload == "sweep" else 32
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
     if args.workload == "single":
@@ -231,6 +237,8 @@ def main():
     coll_dev = "cuda" if backend == "nccl" else "cpu"
 
     nr, nz, M = args.nr, args.nz, args.members
+    if args.workload == "sweep":
+        return bench_sweep(args, xee, torch, dist, rank, local_rank, world, backend, coll_dev)
     operator = "BAROCLINIC" if args.workload == "baroclinic" else "BAROTROPIC"
     prof = xee.profiles(nr, nz, 0, 0, (0.0, 1.0, 0.0, 1.0))
     ens = xee.Ensemble(nr, nz, M, device=local_rank)
@@ -380,6 +388,108 @@ def main():
     ens.close()
     if comm is not None:
         comm.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bench_sweep(args, xee, torch, dist, rank, local_rank, world, backend, coll_dev):
+    """configs[4]: the source-term sweep.  --members timesteps per GPU, six cases per timestep, every input resident
+    (xlab-ee-fortran_amd/sweep.py); a step = both operators x three right-hand sides, each stage assemble/forcing ->
+    solve -> cal_eta -> EE scalars, then the record gather."""
+    from xlab_ee_fortran_amd import ensemble_dp as dp
+    from xlab_ee_fortran_amd import sweep as S
+    nr, nz, nt = args.nr, args.nz, args.members
+    sw = S.Sweep(nr, nz, range(rank * nt, (rank + 1) * nt), device=local_rank, fused=not args.sweep_split)
+
+    def keep(op, rhs, ens, first):                 # member 0 of the (BAROTROPIC, -B) kind, for the golden check (device copy)
+        if op == 0 and rhs == 0:
+            ens.field_save("PSI", 2); ens.field_save("ETA", 2)
+
+    def step():
+        rec = sw.step(args.max_iter, 1e-8, -1.0, 1.0, on_stage=keep)
+        if world > 1:
+            rec = dp.gather_records(rec, world * nt * S.CASES_PER_TIMESTEP, world, rank, device=coll_dev,
+                                    per_rank=nt * S.CASES_PER_TIMESTEP)
+        return rec
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    acc = {}
+    for _ in range(args.steps):
+        rec = step()
+        for key, t in sw.stage_timing.items():
+            a = acc.setdefault(key, {k: 0 for k in t})
+            for k in t:
+                a[k] += t[k]
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if rank == 0:
+        interior = (nr - 2) * (nz - 2)
+        cases = world * nt * S.CASES_PER_TIMESTEP * args.steps
+        nm = sw.ens.members                        # members of one solve stage: nt (split) or 3 nt (fused)
+        kinds = {}
+        for (opn, rhsn), a in acc.items():
+            sweep_s = a["sweep_ms"] * 1e-3
+            kinds[f"{opn}/{rhsn}"] = {
+                "avg_launch_us": sweep_s / max(a["sweep_launches"], 1) * 1e6,
+                "redo_tile_fraction": (a["redo_tiles_total"] + a["inline_redo_tiles"]) / max(a["tiles"], 1),
+                "redo_tiles": a["redo_tiles_total"], "inline_redo_tiles": a["inline_redo_tiles"], "tiles": a["tiles"],
+                "solve_ms_per_stage": a["solve_ms"] / args.steps,
+                "cases_per_s_of_this_stage": nm * args.steps / (a["solve_ms"] * 1e-3) if a["solve_ms"] > 0 else None,
+                "TFLOPs": FLOP_PER_POINT_ITER * interior * nm * a["iterations"] / sweep_s / 1e12 if sweep_s > 0 else None}
+        tot_sweep_s = sum(a["sweep_ms"] for a in acc.values()) * 1e-3
+        tot_launch = sum(a["sweep_launches"] for a in acc.values())
+        tot_pi = float(interior) * nm * sum(a["iterations"] for a in acc.values())
+        tflops = FLOP_PER_POINT_ITER * tot_pi / tot_sweep_s / 1e12 if tot_sweep_s > 0 else 0.0
+        out = {
+            "metric": "diagnosed cases/s (1024x512 r-z grid, damped Jacobi to max_iter, bit-identical to the reference)",
+            "value": cases / dt, "unit": "cases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"[sweep] configs[4]: {nt} timesteps per GPU x 6 cases = {{L(B=0), L(B_t)}} x {{f=-B_t, thermal "
+                                   f"g0/theta0 d/dr(Q/(Cp exner)), f=0 with chi=1e-5 sin(pi z) on the r=1 rim}} at {nr}x{nz}, "
+                                   f"max_iter={args.max_iter}, check every 100 (x8 GPUs x 8 timesteps = the 64 timesteps of configs[4])",
+                       "nr": nr, "nz": nz, "timesteps_per_gpu": nt, "cases_per_gpu": nt * S.CASES_PER_TIMESTEP,
+                       "max_iter": args.max_iter, "parallelism": f"ensemble-dp{world}",
+                       "stages": "six: (operator, kind) one after the other" if args.sweep_split else
+                                 "two: per operator, the three kinds of all timesteps in one batch (they share the operator)"},
+            "all_cases_ran_to_max_iter": bool(np.all(rec["iters"] == args.max_iter)),
+            "roofline": {"bound": "valu", "achieved": tflops, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tflops / VALU_PEAK_TFLOPS, "traffic": None,
+                         "avg_launch_us": tot_sweep_s / max(tot_launch, 1) * 1e6, "launches": tot_launch,
+                         "kernel": "k_sweep_q (both operator bodies; see per_stage)"},
+            "per_stage": kinds,
+        }
+        ens = sw.ens
+        ens.field_restore("PSI", 2); ens.field_restore("ETA", 2)
+        psi0 = ens.download("PSI", 0, 1)[0]
+        eta0 = ens.download("ETA", 0, 1)[0]
+        chk = {"timestep0_BAROTROPIC_minus_B_psi_md5": hashlib.md5(psi0.tobytes()).hexdigest(),
+               "timestep0_BAROTROPIC_minus_B_eta_md5": hashlib.md5(eta0.tobytes()).hexdigest(), "golden": None, "matches_golden": None}
+        try:
+            gh = json.loads((ROOT / "tests" / "golden" / "golden_hashes.json").read_text())
+            key = f"bench_m0_{args.max_iter}"
+            if (nr, nz) == (1024, 512) and key in gh:
+                g = gh[key]["md5"]
+                chk["golden"] = f"tests/golden/golden_hashes.json:{key} (the reference program's own output)"
+                chk["matches_golden"] = bool(g["rchi-[BAROTROPIC]-O.bin"] == chk["timestep0_BAROTROPIC_minus_B_psi_md5"]
+                                             and g["eta-[BAROTROPIC]-A.bin"] == chk["timestep0_BAROTROPIC_minus_B_eta_md5"])
+        except (OSError, ValueError, KeyError):
+            pass
+        out["check"] = chk
+        print(json.dumps(out), flush=True)
+    sw.close()
     if world > 1:
         dist.destroy_process_group()
 

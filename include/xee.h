@@ -270,6 +270,11 @@ typedef struct {
     int64_t redo_tiles;     /* tiles the LAST residual-writing sweep launch left to the exact body (k_sweep_q's optimistic
                                body rejected them: zero residuals, non-finite iterates, exotic coefficients); 0 on the
                                common path -- a diagnostic of how often the fallback runs */
+    int64_t redo_tiles_total;  /* ... summed over ALL residual-writing launches of the last solve */
+    int64_t inline_redo_tiles; /* tiles the plain (not residual-writing) launches redid with the exact body inside their own
+                                  workgroup, summed over the last solve */
+    int64_t tiles;             /* tile executions of the blocked sweep in the last solve (launches x tiles per launch):
+                                  (redo_tiles_total + inline_redo_tiles) / tiles = the fraction that took the exact body */
 } xee_timing_t;
 
 /* flags of xee_ensemble_solve */
@@ -304,6 +309,16 @@ int xee_ensemble_forcing_from_B(xee_ensemble_t *ens);
  * source term of the legacy sweep, old-diagnose/diagnose.f90:383-387,395-406;  f := 0 (:553) */
 int xee_ensemble_forcing_thermal(xee_ensemble_t *ens);
 int xee_ensemble_forcing_zero(xee_ensemble_t *ens);
+/* Device-resident copies of a field (all members): save the current content of `field` (any XEE_F_* below XEE_F_COE0) into
+ * stash slot `slot` (0..63, allocated on first use), or copy a slot back into the field.  A host that cycles through several
+ * right-hand sides or boundary fields per operator -- the source-term sweep, old-diagnose/diagnose.f90:548-673: rchi_bc,
+ * f = 0, f = -dB, f = -B0 in turn -- keeps them in HBM and switches without touching PCIe. */
+/* Member window: the forcing_* calls above and field_save / field_restore below act on members [first, first + count)
+ * only until the window is changed (count = 0: all members again).  Lets one batch hold cases that share an operator
+ * but differ in their right-hand side -- the sweep's {-B, thermal, zero} kinds of one timestep. */
+int xee_ensemble_member_window(xee_ensemble_t *ens, int first, int count);
+int xee_ensemble_field_save(xee_ensemble_t *ens, int field, int slot);
+int xee_ensemble_field_restore(xee_ensemble_t *ens, int field, int slot);
 /* solver coefficients (K1) then the 9-point stencil (K2) for the chosen operator variant */
 int xee_ensemble_assemble(xee_ensemble_t *ens, int variant);
 /* the 9-point stencil (K2) from the solver coefficients CURRENTLY held in XEE_F_SOLVER_A / _B / _C (uploaded, or left by

@@ -137,6 +137,8 @@ struct xee_ensemble {
     float* sums2 = nullptr;
     int* ex_slow2 = nullptr;
     int* redo = nullptr;               // tile list of k_sweep_q's residual-writing launches (xee_sweepq.hip)
+    std::map<int, float*> stash;       // device-resident copies of fields (xee_ensemble_field_save): key = field * 64 + slot
+    int win_first = 0, win_count = 0;  // member window of the forcing_* / field_save / field_restore calls (0 = all members)
     MemberState* st_view = nullptr;    // 4 x members: the sweeps' VIEWS of the member states in the pipelined driver.  The
                                        // state machine of check k writes view k % 4 (on a check stream); the sweeps read the
                                        // view of a check the host has seen finish and switch between launches only, so that
@@ -418,6 +420,7 @@ int xee_ensemble_destroy(xee_ensemble_t* e)
     if (e->st_host2) hipHostFree(e->st_host2);
     if (e->st_view) hipFree(e->st_view);
     if (e->redo) hipFree(e->redo);
+    for (auto& kv : e->stash) if (kv.second) hipFree(kv.second);
     if (e->st_host) hipHostFree(e->st_host);
     if (e->sums_host) hipHostFree(e->sums_host);
     for (auto& ev : e->ev) if (ev) hipEventDestroy(ev);
@@ -545,11 +548,37 @@ int xee_ensemble_device_plane(xee_ensemble_t* e, int field, void** dptr, int* pi
     return XEE_OK;
 }
 
+}  // extern "C"
+
+namespace {
+// the grid of the current member window and the float offset of its first member's plane
+Grid window_grid(const xee_ensemble* e, size_t* off)
+{
+    Grid g = e->g;
+    *off = 0;
+    if (e->win_count > 0) { g.members = e->win_count; *off = (size_t)e->win_first * e->g.plane; }
+    return g;
+}
+}  // namespace
+
+extern "C" {
+
+int xee_ensemble_member_window(xee_ensemble_t* e, int first, int count)
+{
+    if (!e) return fail(XEE_ERR_INVALID_ARGUMENT, "null ensemble");
+    if (count == 0) { e->win_first = 0; e->win_count = 0; return XEE_OK; }
+    if (first < 0 || count < 0 || first + count > e->g.members) return fail(XEE_ERR_INVALID_ARGUMENT, "member_window: range outside the ensemble");
+    e->win_first = first; e->win_count = count;
+    return XEE_OK;
+}
+
 int xee_ensemble_forcing_from_B(xee_ensemble_t* e)
 {
     XCHK(use(e));
     if (!e->B) return fail(XEE_ERR_INVALID_ARGUMENT, "B has not been uploaded");
-    launch_negate(e->g, e->B, e->f, e->stream);
+    size_t off;
+    const Grid g = window_grid(e, &off);
+    launch_negate(g, e->B + off, e->f + off, e->stream);
     return check_launch("negate");
 }
 
@@ -559,14 +588,52 @@ int xee_ensemble_forcing_thermal(xee_ensemble_t* e)
     if (!e->have_profiles) return fail(XEE_ERR_INVALID_ARGUMENT, "profiles not set");
     if (!e->Q) return fail(XEE_ERR_INVALID_ARGUMENT, "Q has not been uploaded");
     XCHK(alloc_planes(e, &e->terms));
-    launch_rhs_thermal(e->g, e->Q, e->ra, e->exner, e->terms, e->f, e->stream);
+    size_t off;
+    const Grid g = window_grid(e, &off);
+    launch_rhs_thermal(g, e->Q + off, e->ra, e->exner, e->terms + off, e->f + off, e->stream);
     return check_launch("forcing_thermal");
 }
 
 int xee_ensemble_forcing_zero(xee_ensemble_t* e)
 {
     XCHK(use(e));
-    HIPCHK(hipMemsetAsync(e->f, 0, sizeof(float) * e->g.plane * e->g.members, e->stream));
+    size_t off;
+    const Grid g = window_grid(e, &off);
+    HIPCHK(hipMemsetAsync(e->f + off, 0, sizeof(float) * g.plane * g.members, e->stream));
+    return XEE_OK;
+}
+
+int xee_ensemble_field_save(xee_ensemble_t* e, int field, int slot)
+{
+    XCHK(use(e));
+    if (field < 0 || field >= XEE_F_COE0 || slot < 0 || slot > 63) return fail(XEE_ERR_INVALID_ARGUMENT, "field_save: field below XEE_F_COE0, slot 0..63");
+    float* src = nullptr;
+    int n1 = 0, n2 = 0;
+    XCHK(field_ref(e, field, &src, &n1, &n2));
+    float*& dst = e->stash[field * 64 + slot];
+    const size_t bytes = sizeof(float) * e->g.plane * e->g.members;
+    if (!dst) {
+        if (hipMalloc(reinterpret_cast<void**>(&dst), bytes) != hipSuccess) { dst = nullptr; return fail(XEE_ERR_ALLOC, "hipMalloc stash slot"); }
+        HIPCHK(hipMemsetAsync(dst, 0, bytes, e->stream));
+    }
+    size_t off;
+    const Grid g = window_grid(e, &off);
+    HIPCHK(hipMemcpyAsync(dst + off, src + off, sizeof(float) * g.plane * g.members, hipMemcpyDeviceToDevice, e->stream));
+    return XEE_OK;
+}
+
+int xee_ensemble_field_restore(xee_ensemble_t* e, int field, int slot)
+{
+    XCHK(use(e));
+    if (field < 0 || field >= XEE_F_COE0 || slot < 0 || slot > 63) return fail(XEE_ERR_INVALID_ARGUMENT, "field_restore: field below XEE_F_COE0, slot 0..63");
+    auto it = e->stash.find(field * 64 + slot);
+    if (it == e->stash.end() || !it->second) return fail(XEE_ERR_INVALID_ARGUMENT, "field_restore: nothing was saved in this slot");
+    float* dst = nullptr;
+    int n1 = 0, n2 = 0;
+    XCHK(field_ref(e, field, &dst, &n1, &n2));
+    size_t off;
+    const Grid g = window_grid(e, &off);
+    HIPCHK(hipMemcpyAsync(dst + off, it->second + off, sizeof(float) * g.plane * g.members, hipMemcpyDeviceToDevice, e->stream));
     return XEE_OK;
 }
 
@@ -686,6 +753,7 @@ int solve_pipelined(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float 
     std::vector<int> stop_slot(g.members, -1);    // snapshot slot holding a stopped member's result
     std::vector<char> active(g.members, 1);
     e->timing = xee_timing_t{};
+    if (e->redo) HIPCHK(hipMemsetAsync(e->redo + sweep_q_redo_ints(g) - 2, 0, 2 * sizeof(int), s));   // the solve's diagnostic counters
     HIPCHK(hipEventRecord(e->ev[0], s));
     int cnt = 0, k = 0;                           // k = number of checks enqueued
     int digested = 0;                             // ... and of checks whose outcome the host has looked at
@@ -716,7 +784,7 @@ int solve_pipelined(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float 
     // Graphs.  A small batch is bound by how fast the host enqueues (one 1024x512 case: 13 launches of ~9 us per block
     // and eight more per check): a whole block -- the launches between two checks -- is captured once per distinct set
     // of arguments (ping-pong phase x slot x view: at most 2 x 3 x 4) and replayed as a graph.
-    struct BlockGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; bool snapped = false; int launches = 0; };
+    struct BlockGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; bool snapped = false; int launches = 0; long long tiles = 0; };
     struct GraphCache {
         std::map<int, BlockGraph> m;
         ~GraphCache() { for (auto& kv : m) { if (kv.second.exec) hipGraphExecDestroy(kv.second.exec); if (kv.second.graph) hipGraphDestroy(kv.second.graph); } }
@@ -729,9 +797,9 @@ int solve_pipelined(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float 
         HIPCHK(hipMemsetAsync(e->redo, 0, sizeof(int) * sweep_q_redo_ints(g), s));
     }
     // the launches from iteration `from` up to `target` (a check iteration gets the residual plane and the snapshot)
-    auto enqueue_sweeps = [&](int from, int target, bool to_check, int sl, int* cur_io, bool* snapped, int* launches) {
+    auto enqueue_sweeps = [&](int from, int target, bool to_check, int sl, int* cur_io, bool* snapped, int* launches, long long* tiles) {
         int c2 = from;
-        *snapped = false; *launches = 0;
+        *snapped = false; *launches = 0; *tiles = 0;
         while (c2 < target) {
             // a block that is not a whole number of launches starts with the short one: the residual-writing launch at its
             // end then is a full-length one (at 4 iterations it was HBM-bound by its three stores per point: 113 us for
@@ -740,6 +808,7 @@ int solve_pipelined(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float 
             const int n = rem ? rem : tb_T;
             c2 += n;
             const bool check = to_check && c2 == target;
+            e->last_sweep.tiles = 0;
             if (n == 1)
                 launch_sweep(g, e->psi[*cur_io], e->psi[*cur_io ^ 1], e->coe, e->f, check ? resbuf[sl] : nullptr, view, alpha, s);
             else if (launch_blocked(e, e->psi[*cur_io], e->psi[*cur_io ^ 1], check ? resbuf[sl] : nullptr, alpha, n, view,
@@ -747,6 +816,7 @@ int solve_pipelined(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float 
                 *snapped = true;
             *cur_io ^= 1;
             *launches += 1;
+            *tiles += e->last_sweep.tiles;
         }
         if (to_check && !*snapped) launch_copy_active(g, e->psi[*cur_io], snapbuf[sl], view, s);   // the iterate this check belongs to
     };
@@ -763,13 +833,14 @@ int solve_pipelined(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float 
         view = e->st_view + (size_t)vi * g.members;
         bool snapped = false;
         int launches = 0;
+        long long tiles = 0;
         if (use_graphs && check && cnt % cs == 0) {
             const int key = cur | (sl << 1) | (vi << 3);
             BlockGraph& bg = graphs.m[key];
             if (!bg.exec) {
                 int c2 = cur;
                 if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess) {
-                    enqueue_sweeps(cnt, target, true, sl, &c2, &bg.snapped, &bg.launches);
+                    enqueue_sweeps(cnt, target, true, sl, &c2, &bg.snapped, &bg.launches, &bg.tiles);
                     if (hipStreamEndCapture(s, &bg.graph) != hipSuccess || hipGraphInstantiate(&bg.exec, bg.graph, nullptr, nullptr, 0) != hipSuccess)
                         bg.exec = nullptr;
                 }
@@ -779,12 +850,13 @@ int solve_pipelined(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float 
         if (use_graphs && check && cnt % cs == 0) {
             BlockGraph& bg = graphs.m[cur | (sl << 1) | (vi << 3)];
             HIPCHK(hipGraphLaunch(bg.exec, s));
-            snapped = bg.snapped; launches = bg.launches;
+            snapped = bg.snapped; launches = bg.launches; tiles = bg.tiles;
             cur ^= (launches & 1);
         } else {
-            enqueue_sweeps(cnt, target, check, sl, &cur, &snapped, &launches);
+            enqueue_sweeps(cnt, target, check, sl, &cur, &snapped, &launches, &tiles);
         }
         e->timing.sweep_launches += launches;
+        e->timing.tiles += tiles;
         e->timing.iterations += target - cnt;
         cnt = target;
         if (check) {
@@ -851,7 +923,12 @@ int solve_pipelined(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float 
         HIPCHK(hipMemcpyAsync(e->psi[cur] + (size_t)m * g.plane, snapbuf[stop_slot[m]] + (size_t)m * g.plane,
                               sizeof(float) * g.plane, hipMemcpyDeviceToDevice, s));
     }
-    if (e->redo) { int n = 0; HIPCHK(hipMemcpyAsync(&n, e->redo + sweep_q_redo_ints(g) - 1, sizeof(int), hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s)); e->timing.redo_tiles = n; }
+    if (e->redo) {
+        int n[3] = {0, 0, 0};                     // last launch's redo list, all lists of the solve, in-workgroup fallbacks
+        HIPCHK(hipMemcpyAsync(n, e->redo + sweep_q_redo_ints(g) - 3, sizeof(n), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        e->timing.redo_tiles = n[0]; e->timing.redo_tiles_total = n[1]; e->timing.inline_redo_tiles = n[2];
+    }
     // XEE_F_RESIDUAL = the residual plane of each member's LAST check (include/xee.h): checks rotated through the
     // slots' planes; a stopped member's is the one of its stopping check, everyone else's the one of the last check enqueued
     for (int m = 0; m < g.members && k >= 1; ++m) {
@@ -916,6 +993,7 @@ int xee_ensemble_solve(xee_ensemble_t* e, int max_iter, int check_step, int conv
     }
 
     e->timing = xee_timing_t{};
+    if (e->redo) HIPCHK(hipMemsetAsync(e->redo + sweep_q_redo_ints(g) - 2, 0, 2 * sizeof(int), s));
     HIPCHK(hipEventRecord(e->ev[0], s));
     bool block_open = false;
     int cnt = 0;
@@ -929,12 +1007,14 @@ int xee_ensemble_solve(xee_ensemble_t* e, int max_iter, int check_step, int conv
         const bool check = cnt == next_check;
         const bool last = cnt == max_iter;
         if (!block_open) { HIPCHK(hipEventRecord(e->ev[2], s)); block_open = true; }
+        e->last_sweep.tiles = 0;
         if (n == 1)
             launch_sweep(g, e->psi[cur], e->psi[cur ^ 1], e->coe, e->f, check ? e->res : nullptr, e->st, alpha, s);
         else
             launch_blocked(e, e->psi[cur], e->psi[cur ^ 1], check ? e->res : nullptr, alpha, n);
         cur ^= 1;
         e->timing.sweep_launches += 1;
+        e->timing.tiles += e->last_sweep.tiles;
         e->timing.iterations += n;
         if (check) {
             HIPCHK(hipEventRecord(e->ev[3], s));
@@ -973,6 +1053,11 @@ int xee_ensemble_solve(xee_ensemble_t* e, int max_iter, int check_step, int conv
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, e->ev[0], e->ev[1]));
     e->timing.solve_ms = ms;
+    if (e->redo) {
+        int n[3] = {0, 0, 0};
+        HIPCHK(hipMemcpy(n, e->redo + sweep_q_redo_ints(g) - 3, sizeof(n), hipMemcpyDeviceToHost));
+        e->timing.redo_tiles = n[0]; e->timing.redo_tiles_total = n[1]; e->timing.inline_redo_tiles = n[2];
+    }
 
     // :259-264  every member's result into one plane.  A stopped member's planes are never touched
     // again, so its result still sits in the plane its last launch wrote.
@@ -1252,6 +1337,7 @@ int tier1_reset(xee_ensemble* e)
     e->uv = UniformVals{};
     e->dr = e->dz = 0.f;
     e->cur = 0;
+    e->win_first = e->win_count = 0;
     e->first_case_id = 0;
     e->timing = xee_timing_t{};
     e->last_sweep = SweepDesc{};

@@ -95,6 +95,7 @@ struct SweepOpts {
 struct SweepDesc {
     const char* name = "none";
     int T = 0, tile_w = 0, tile_h = 0;
+    long long tiles = 0;   // tiles (workgroups with work) of the last launch
 };
 // coefficient planes that hold one bit pattern over the interior of every member (set by assemble)
 struct UniformVals {

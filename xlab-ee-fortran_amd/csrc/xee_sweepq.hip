@@ -18,8 +18,8 @@
 //     dynamic  max(2^-100, dmax*2^-120) <= |alpha*R| <= min(2^100, dmin*2^94) at every interior point
 //              and every one of the T steps (running max/min of |alpha*R|: one v_max3/v_min3 per two points),
 //              and every value of the tile finite at the end (non-finite values are sticky under the update)
-//              (round 2: a residual that is EXACTLY zero is admitted where it provably is harmless -- see "Zero
-//              residuals" below; converged regions produce them by the thousand late in a long run)
+//              (a residual that is EXACTLY zero is admitted -- see "Zero residuals" below; converged regions produce them
+//              by the thousand late in a long run, zero right-hand sides from the first iteration on)
 // which keeps the exponent difference below the 96 where div_scale starts to rescale and quotient,
 // reciprocal and remainders normal and exactly representable (tests/test_gpu_quotient.py checks the
 // identity over 10^9 operand pairs drawn over the whole admitted range).  A tile that fails any of it (a
@@ -28,24 +28,32 @@
 //
 // The same validation covers two more savings:
 //  * BAROTROPIC operator (b = 0): its four corner weights are +-0 (elliptic_tools.f90:46,48,52,54 with
-//    BX = BY = 0), and `s + (+-0)*x` differs from s only when x is not finite or the partial sum is itself
-//    a zero -- in which case either a non-finite value is in the tile at the end, or every later term
-//    vanished too and alpha*R = 0 fails the dynamic bound.  The optimistic body sums the five-point star
-//    only (5 mul + 5 add instead of 9 + 9).
+//    BX = BY = 0).  The optimistic body sums the five-point star only (5 mul + 5 add instead of 9 + 9).  With finite
+//    iterates the four dropped products are zeros, and adding a zero changes a partial sum only if that sum is itself a
+//    zero (its sign): by induction over the nine terms the star's sum S5 and the reference's S9 are the same bits unless
+//    both are zeros of different sign -- and S5 is -0 only if all five products are -0 (a cancellation x + (-x) and any
+//    +0 term give +0), S9 only if all nine are.  So S5 != S9 needs S5 = -0; then R = S - f is the same for f != 0, and for
+//    f = +-0 a zero whose sign may differ, which cannot change psi + a/d unless psi is -0 (excluded, see below).  The one
+//    place where the sign is visible is the residual plane a residual-writing launch stores: a lane that sees S5 = -0 in
+//    that launch's last step fails the tile.  (A non-finite iterate makes a dropped product NaN: it is in the tile at the
+//    end, non-finite values being sticky under the update, and fails the tile too.)
 //  * no select for the points that never update (rim, outside the domain): their weights are set to 0, f
 //    to -1 and y1 to the zero whose sign makes q2 = -0, so `psi + q2` returns psi bit for bit and their
 //    "residual" alpha*1 stays inside the dynamic bound.
 //
 // Zero residuals.  A point whose residual is exactly zero has a = alpha*R = +-0 and both forms of the quotient give a
 // zero; psi + (+-0) is psi for either sign unless psi is -0.  An update cannot create a -0 (x + y is -0 only for
-// -0 + -0), so a lane whose loaded interior psi hold no -0 may take zeros -- PROVIDED nothing in (0, a_lo) can hide
-// behind them, which the running minimum of |a| can no longer tell.  It cannot where f is not tiny: R = fl(s - f) of two
+// -0 + -0), so a lane whose loaded interior psi hold no -0 may take zeros (a lane that loaded one fails the tile) --
+// PROVIDED nothing in (0, a_lo) hides behind them.  Where f is not tiny nothing can: R = fl(s - f) of two
 // floats is either zero or at least |f| * 2^-25 (opposite signs or a factor two apart: more than |f|/2; within a factor
 // two: an exact, non-zero multiple of the smaller one's ulp), so with fmin = min |f| over the lane's interior points and
-// |alpha| * fmin * 2^-26 >= a_lo every non-zero |a| is above the lower bound by construction and the minimum need not be
-// looked at.  (The five-point star's argument above needs a = 0 to be rejected only when f = 0 as well: then fmin = 0
-// and the lane keeps the strict rule.)  Without this, 2-3 % of the tiles of the bench's ensemble fell to the exact body
-// from ~5,000 iterations on, and the stragglers stretched every launch by 12 % (profiles/r02).
+// |alpha| * fmin * 2^-26 >= a_lo every non-zero |a| is above the lower bound by construction and no minimum is kept
+// (waves of such lanes run a loop instance without it).  Elsewhere -- f = 0: the boundary-driven solves of the legacy
+// sweep, old-diagnose/diagnose.f90:548-568 -- the running minimum is taken over the NON-ZERO |a| only (an unsigned
+// minimum of (bits << 1) - 1: three instructions per pair and step).  Round 2 rejected every zero where f = 0: a
+// zero right-hand side then ran 13 % of its tiles twice (58 instead of 35 us per launch of 8 cases, profiles/r03).
+// Without the first rule, 2-3 % of the tiles of the bench's ensemble fell to the exact body from ~5,000 iterations on,
+// and the stragglers stretched every launch by 12 % (profiles/r02).
 //
 // Round 2: the optimistic body is written in PACKED fp32 (v_pk_mul/add/fma_f32: two points per instruction, each
 // half rounded separately -- the same bits as two scalar operations).  A lane's R rows are paired (k, k + R/2), so the
@@ -165,6 +173,7 @@ __device__ __forceinline__ bool fast_tile(const Grid& g, const TileGeom& tg, flo
     float dmin = 0x1p120f, dmax = 0x1p-120f;            // extremes of |coe5| over this lane's interior points
     float fmin = __builtin_inff();                      // min |f| over them, and whether one of their psi is -0
     bool neg_zero_psi = false;
+    unsigned nonzero_bits = 0u;                         // OR of every loaded psi's bits and every interior |f|'s: 0 = "all +0 / +-0"
     {
         // Every load of the tile is issued before the first value is used, unconditionally and from a
         // clamped (always valid) address; what lies outside the domain is replaced afterwards.  Row offsets are
@@ -243,6 +252,7 @@ __device__ __forceinline__ bool fast_tile(const Grid& g, const TileGeom& tg, flo
             dmax = interior ? __builtin_fmaxf(dmax, __builtin_fabsf(d)) : dmax;
             fmin = interior ? __builtin_fminf(fmin, __builtin_fabsf(rf[r])) : fmin;
             neg_zero_psi = neg_zero_psi || (interior && __builtin_bit_cast(unsigned, rp[r]) == 0x80000000u);
+            nonzero_bits |= __builtin_bit_cast(unsigned, pw[r]) | (interior ? (__builtin_bit_cast(unsigned, rf[r]) & 0x7fffffffu) : 0u);
             cq_m = Cp;
             by_m = BYp;
         }
@@ -258,7 +268,12 @@ __device__ __forceinline__ bool fast_tile(const Grid& g, const TileGeom& tg, flo
     }
 
     stamp<STAMP>(tg, 2);                                  // weights built
-    float amax = 0.0f, amin = __builtin_inff();           // running extremes of |alpha * R|
+    // running extremes of |alpha * R|.  The minimum is taken over the NON-ZERO values only (see "Zero residuals"): as an
+    // unsigned minimum of (bits << 1) - 1, which drops the sign, keeps the order of the magnitudes and sends both zeros to
+    // 0xffffffff (v_lshl_add_u32 + v_min3_u32: three instructions per pair)
+    float amax = 0.0f;
+    unsigned amin_nz = 0xffffffffu;
+    bool zero_at_last = false;                            // residual-writing star body: a sum that is -0 in the launch's last step
     f2 q[H2], rl[WRITE_R ? H2 : 1];
     const f2 alpha2 = f2{alpha, alpha};
     // One Jacobi step src -> dst.  The edge rows of src are already in LDS (written by the tail of the previous
@@ -288,11 +303,18 @@ __device__ __forceinline__ bool fast_tile(const Grid& g, const TileGeom& tg, flo
             above = (w < NW - 1) ? edge[par][1][w + 1][lane] : 0.0f;
         }
         auto finish = [&](int k, f2 Rv) {
+            // (the residual-writing star body: its sum and the reference's nine-term sum can differ in one way only, the sign
+            // of a zero, and only when the star's own sum is -0, i.e. all five products are -0 -- see "Zero residuals")
+            if constexpr (WRITE_R && LAST && BARO)
+                zero_at_last = zero_at_last || __builtin_bit_cast(unsigned, Rv.x) == 0x80000000u || __builtin_bit_cast(unsigned, Rv.y) == 0x80000000u;
             Rv = Rv - ff[k];                                           // :190
             const f2 a = ALPHA1 ? Rv : alpha2 * Rv;
             dst[k] = src[k] + quotient_q2(a, c[K5][k], y1[k]);         // :238, -d = coe5
             amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(a.x)), __builtin_fabsf(a.y));
-            if constexpr (TRACK_MIN) amin = __builtin_fminf(__builtin_fminf(amin, __builtin_fabsf(a.x)), __builtin_fabsf(a.y));
+            if constexpr (TRACK_MIN) {
+                const unsigned ux = (__builtin_bit_cast(unsigned, a.x) << 1) + 0xffffffffu, uy = (__builtin_bit_cast(unsigned, a.y) << 1) + 0xffffffffu;
+                amin_nz = __builtin_elementwise_min(__builtin_elementwise_min(amin_nz, ux), uy);
+            }
             if constexpr (WRITE_R && LAST) rl[k] = Rv;
         };
         if constexpr (BARO) {
@@ -346,13 +368,49 @@ __device__ __forceinline__ bool fast_tile(const Grid& g, const TileGeom& tg, flo
     };
     edge[0][0][w][lane] = p[H2 - 1].y;
     edge[0][1][w][lane] = p[0].x;
-    // Where zeros may pass (see "Zero residuals" in the header) the lower bound holds by construction and the running
+    // Where every non-zero |a| is above the lower bound by construction (see "Zero residuals" in the header) the running
     // minimum is never looked at: a WAVE whose lanes all are in that position runs the instance of the loop that does not
-    // keep it (one v_min3 per pair and step less, ~5 % of the loop).  The choice is wave-uniform; both instances meet
-    // the workgroup's barriers the same number of times.
+    // keep it (three instructions per pair and step less).  The choice is wave-uniform; both instances meet the
+    // workgroup's barriers the same number of times.
     const float a_lo = __builtin_fmaxf(0x1p-100f, dmax * 0x1p-120f);
-    const bool zero_ok = !neg_zero_psi && __builtin_fabsf(alpha) * fmin * 0x1p-26f >= a_lo;
+    const bool zero_ok = __builtin_fabsf(alpha) * fmin * 0x1p-26f >= a_lo;
     bool in_q;
+
+    // All-zero tiles.  A zero right-hand side with a boundary-driven solution (old-diagnose/diagnose.f90:548-568: f = 0,
+    // rchi = rchi_bc) leaves most of the plane at the all-zero first guess for thousands of iterations.  If EVERY psi the
+    // tile loaded (halo and rim included) is +0 and every interior f is +-0, one step decides all T of them: a Jacobi step
+    // is a function of the tile's values, so if it returns +0 everywhere again, so does every later one.  The step is
+    // computed for real (a non-finite weight, 0 * inf, would show as a NaN) and checked; its residual is the residual of
+    // every step.  One extra barrier per tile for the vote (the waves are in step here: it costs its own latency only).
+    bool zero_tile = false;
+    {
+        const bool wave_zero = __builtin_amdgcn_ballot_w64(nonzero_bits != 0u) == 0;
+        if (lane == 0) vote[w] = wave_zero ? 0 : 1;
+        __syncthreads();
+        const int v0 = vote[lane % NW];
+        if (__builtin_amdgcn_ballot_w64(v0 != 0) == 0) {
+            step(p, q, 0, std::integral_constant<bool, WRITE_R>{}, std::false_type{});
+            bool z = true;
+#pragma unroll
+            for (int k = 0; k < H2; ++k)
+                z = z && __builtin_bit_cast(unsigned, q[k].x) == 0u && __builtin_bit_cast(unsigned, q[k].y) == 0u;
+            // (vote[] again: every wave has read it before the barrier at the head of the step)
+            const bool wave_bad = __builtin_amdgcn_ballot_w64(!z) != 0;
+            if (lane == 0) vote[w] = wave_bad ? 1 : 0;
+            __syncthreads();
+            const int v1 = vote[lane % NW];
+            if (__builtin_amdgcn_ballot_w64(v1 != 0) != 0) return false;   // exotic weights: the exact body decides
+            if constexpr (WRITE_R && BARO) {
+                // the star's sum of signed zeros need not have the sign of the reference's nine-term sum, whose third term
+                // (+0) * (+0) makes it +0, and +0 - (+-0) = +0 (elliptic_tools.f90:77-85,190 with :46-54 for b = 0)
+#pragma unroll
+                for (int k = 0; k < H2; ++k) rl[k] = f2{0.0f, 0.0f};
+            }
+            zero_tile = true;                             // p holds the result already: all +0
+        }
+    }
+
+    if (!zero_tile) {
     // (the loop is written out once per instance -- a macro, not a lambda around `step`: with one more closure level the
     // iterate's register arrays were left in scratch memory)
 #define XEE_Q_RUN(TRACK)                                                                                           \
@@ -390,9 +448,12 @@ __device__ __forceinline__ bool fast_tile(const Grid& g, const TileGeom& tg, flo
     {
         bool ok = dmin >= 0x1p-120f && dmax <= 0x1p120f;
         const float a_hi = __builtin_fminf(0x1p100f, dmin * 0x1p94f);
-        // (see "Zero residuals" in the header: where every non-zero |a| is above a_lo by construction, zeros may pass --
-        // and a wave of such lanes only did not keep amin, which still is +inf)
-        ok = ok && (zero_ok || amin >= a_lo) && amax <= a_hi;
+        // Lower bound: by construction where zero_ok, else the smallest NON-ZERO |a| seen (a wave of zero_ok lanes did not
+        // keep it: still "none").  Zeros pass unless a psi the lane loaded is -0 (see "Zero residuals"); in the residual-
+        // writing star body a sum of -0 in the last step is left to the exact body too, for the sign of the stored residual.
+        const bool none = amin_nz == 0xffffffffu;
+        const bool lo_ok = zero_ok || none || amin_nz + 1u >= (__builtin_bit_cast(unsigned, a_lo) << 1);
+        ok = ok && !neg_zero_psi && lo_ok && !zero_at_last && amax <= a_hi;
 #pragma unroll
         for (int k = 0; k < H2; ++k) {
             const f2 v = p[k];
@@ -404,6 +465,7 @@ __device__ __forceinline__ bool fast_tile(const Grid& g, const TileGeom& tg, flo
         __syncthreads();
         const int v = vote[lane % NW];
         if (__builtin_amdgcn_ballot_w64(v != 0) != 0) return false;
+    }
     }
     stamp<STAMP>(tg, 4);                                  // validated
     {
@@ -587,7 +649,7 @@ template <int NW, int R, bool WRITE_R, bool BARO, bool ALPHA1, bool STAMP = fals
 __global__ __launch_bounds__(NW * 64, (BARO || NW * R < 64) ? 4 : 1) void k_sweep_q(Grid g, const float* __restrict__ psi_in,
         float* __restrict__ psi_out, const float* __restrict__ base, const float* __restrict__ f,
         float* __restrict__ res, float* __restrict__ snap, const MemberState* __restrict__ st, float alpha, int T, int exact_only,
-        int* __restrict__ redo, unsigned long long* __restrict__ stamps, int ntx, int nty)
+        int* __restrict__ redo, unsigned long long* __restrict__ stamps, int ntx, int nty, int cnt_slot)
 {
     __shared__ float edge[2][2][NW][64];
     __shared__ int vote[NW];
@@ -624,6 +686,7 @@ __global__ __launch_bounds__(NW * 64, (BARO || NW * R < 64) ? 4 : 1) void k_swee
             redo[1 + slot] = tile;                         // = (member * nty + row) * ntx + column
         }
     } else {
+        if (threadIdx.x == 0 && redo && !exact_only) atomicAdd(redo + cnt_slot + 3, 1);   // diagnostic: in-workgroup fallbacks
         exact_tile<NW, R, WRITE_R, BARO>(g, tg, edge, psi_in, psi_out, base, f, res, snap, alpha, T, member);
     }
     stamp<STAMP>(tg, 6);
@@ -645,11 +708,11 @@ __global__ __launch_bounds__(NW * 64) void k_sweep_q_redo(Grid g, const float* _
         __syncthreads();                                  // the edge rows are reused by the next tile
     }
     // the list is consumed: the last workgroup to get here empties it for the next residual-writing launch
-    // (redo[done_slot] counts arrivals, redo[done_slot + 1] keeps the count for xee_timing_t.redo_tiles; every workgroup
-    // has read redo[0] before it arrives)
+    // (redo[done_slot] counts arrivals, redo[done_slot + 1] keeps the count for xee_timing_t.redo_tiles, [done_slot + 2]
+    // their sum since the solve began; every workgroup has read redo[0] before it arrives)
     if (threadIdx.x == 0) {
         __threadfence();
-        if (atomicAdd(redo + done_slot, 1) == (int)gridDim.x - 1) { redo[done_slot + 1] = count; redo[0] = 0; redo[done_slot] = 0; __threadfence(); }
+        if (atomicAdd(redo + done_slot, 1) == (int)gridDim.x - 1) { redo[done_slot + 1] = count; redo[done_slot + 2] += count; redo[0] = 0; redo[done_slot] = 0; __threadfence(); }
     }
 }
 
@@ -711,18 +774,19 @@ __global__ __launch_bounds__(256) void k_quotient_check(unsigned long long seed,
 
 template <int NW, int R, bool BARO>
 static void launch_q_cfg(const Grid& g, const float* psi_in, float* psi_out, const float* base, const float* f,
-                         float* res, float* snap, const MemberState* st, float alpha, int T, int exact_only, int* redo, hipStream_t s)
+                         float* res, float* snap, const MemberState* st, float alpha, int T, int exact_only, int* redo, SweepDesc* desc, hipStream_t s)
 {
     constexpr int H = NW * R;
     const int ntx = (g.nx - 1 + (64 - 2 * T) - 1) / (64 - 2 * T), nty = (g.ny - 1 + (H - 2 * T) - 1) / (H - 2 * T);
     const long long ntile = (long long)ntx * nty * g.members;
     const dim3 grid((unsigned)(8 * ((ntile + 7) / 8)));    // one-dimensional, a multiple of eight: see the kernel's tile order
     const bool a1 = alpha == 1.0f;     // the protocol's damping: 1.0f * x is x, the multiply is not issued
-#define Q_LAUNCH(WR, A1) hipLaunchKernelGGL((k_sweep_q<NW, R, WR, BARO, A1>), grid, dim3(NW * 64), 0, s, g, psi_in, psi_out, base, f, res, snap, st, alpha, T, exact_only, redo, (unsigned long long*)nullptr, ntx, nty)
+#define Q_LAUNCH(WR, A1) hipLaunchKernelGGL((k_sweep_q<NW, R, WR, BARO, A1>), grid, dim3(NW * 64), 0, s, g, psi_in, psi_out, base, f, res, snap, st, alpha, T, exact_only, redo, (unsigned long long*)nullptr, ntx, nty, (int)sweep_q_redo_ints(g) - 4)
+    if (desc) desc->tiles = ntile;
     if (res) {                         // (redo[0] is zero here: zeroed at allocation, and by every k_sweep_q_redo when it ends)
         if (a1) Q_LAUNCH(true, true); else Q_LAUNCH(true, false);
         hipLaunchKernelGGL((k_sweep_q_redo<NW, R, BARO>), dim3(exact_only ? 1024 : 64), dim3(NW * 64), 0, s, g, psi_in, psi_out, base, f, res, snap, st,
-                           alpha, T, redo, ntx, nty, (int)sweep_q_redo_ints(g) - 2);
+                           alpha, T, redo, ntx, nty, (int)sweep_q_redo_ints(g) - 4);
     }
     else { if (a1) Q_LAUNCH(false, true); else Q_LAUNCH(false, false); }
 #undef Q_LAUNCH
@@ -731,8 +795,9 @@ static void launch_q_cfg(const Grid& g, const float* psi_in, float* psi_out, con
 size_t sweep_q_redo_ints(const Grid& g)
 {
     // the count, one slot per tile of the densest tiling launch_sweep_q admits (tile steps >= 16 columns, >= 8 rows), the
-    // redo kernel's arrival counter and the last launch's count (diagnostic); the caller zeroes the buffer once
-    return (size_t)g.members * ((g.nx + 15) / 16) * ((g.ny + 7) / 8) + 3;
+    // redo kernel's arrival counter, the last launch's count, the count summed over the solve and the number of tiles the
+    // plain launches redid inside their workgroup (diagnostics: the last four ints); the caller zeroes the buffer once
+    return (size_t)g.members * ((g.nx + 15) / 16) * ((g.ny + 7) / 8) + 5;
 }
 
 bool launch_sweep_q(const Grid& g, const float* psi_in, float* psi_out, const float* base, const float* f,
@@ -752,8 +817,8 @@ bool launch_sweep_q(const Grid& g, const float* psi_in, float* psi_out, const fl
     if ((cfg / 100) * (cfg % 100) - 2 * T < 8) cfg = 808;           // the tile must keep a useful core
     if (desc) { desc->name = barotropic ? "k_sweep_q<star>" : "k_sweep_q<nine>"; desc->T = T; desc->tile_w = 64; desc->tile_h = (cfg / 100) * (cfg % 100); }
 #define Q_CASE(NW, R) case NW * 100 + R: \
-        if (barotropic) launch_q_cfg<NW, R, true>(g, psi_in, psi_out, base, f, res, snap, st, alpha, T, exact_only, redo, s); \
-        else launch_q_cfg<NW, R, false>(g, psi_in, psi_out, base, f, res, snap, st, alpha, T, exact_only, redo, s); \
+        if (barotropic) launch_q_cfg<NW, R, true>(g, psi_in, psi_out, base, f, res, snap, st, alpha, T, exact_only, redo, desc, s); \
+        else launch_q_cfg<NW, R, false>(g, psi_in, psi_out, base, f, res, snap, st, alpha, T, exact_only, redo, desc, s); \
         break;
     switch (cfg) {
         Q_CASE(8, 8)

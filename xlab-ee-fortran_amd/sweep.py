@@ -10,8 +10,8 @@ every solve independent and started from its own bc_init:
 = 6 cases per timestep, case id = 6*t + 3*operator + rhs.  Each case yields eta and the EE scalars
 sum_Q, sum_Qeta, efficiency (old-diagnose :1029-1092, :792-793) in its 128-byte record.
 
-Timesteps are the ensemble members of one GPU batch (`Ensemble(nr, nz, n_local_timesteps)`): a
-solve stage runs for all local timesteps at once; ranks own blocks of timesteps
+The cases of this rank's timesteps are the members of one GPU batch (class Sweep: the three kinds of a
+timestep share their operator and are solved together); ranks own blocks of timesteps
 (ensemble_dp.partition) and only exchange the records (ensemble_dp.gather_records).
 Host-side orchestration only -- every numerical stage is a libxee call.
 """
@@ -43,52 +43,117 @@ def rim_bc(nr, nz):
     return bc
 
 
+class Sweep:
+    """This rank's block of timesteps, resident on the GPU.  __init__ uploads every input; step() runs the stages and
+    touches no host field (bench.py times it).
+
+    fused=True (default): ONE batch of 3 x n_timesteps members -- member rhs * n_timesteps + k is right-hand-side kind rhs
+    of local timestep k -- so that the three kinds of a timestep, which share their operator, are solved together: two
+    stages (one per operator) of 3 n cases each fill the GPU better than six stages of n.  The boundary field never
+    changes (zero for the first two kinds, the rim field for the third) and the forcing is rebuilt per stage through the
+    member window.  fused=False runs the six (operator, kind) stages one after the other on n_timesteps members: the same
+    results, and per-kind timing (stage_timing) for diagnostics."""
+
+    def __init__(self, nr, nz, timesteps, *, device=-1, domain=(0.0, 1.0, 0.0, 1.0), options=None, fused=True):
+        self.nr, self.nz, self.timesteps, self.fused = nr, nz, list(timesteps), fused
+        n = len(self.timesteps)
+        self.ens = X.Ensemble(nr, nz, 3 * n if fused else n, device=device)
+        ens = self.ens
+        for k, v in (options or {}).items():
+            ens.set_option(k, v)
+        ens.set_profiles(X.profiles(nr, nz, 0, 0, domain))
+        Q = heating_Q(nr, nz)
+        rim = rim_bc(nr, nz)
+        zero = np.zeros((nz, nr), np.float32)
+        for k, t in enumerate(self.timesteps):
+            A, B, Cc, _ = ensemble_member(nr, nz, t)
+            for rhs in (range(3) if fused else (0,)):
+                m = rhs * n + k
+                ens.upload("A", A, first=m); ens.upload("B", B, first=m); ens.upload("C", Cc, first=m)
+                ens.upload("Q", Q, first=m)
+                ens.upload("BC_INIT", rim if (fused and rhs == 2) else zero, first=m)
+        if not fused:
+            ens.field_save("BC_INIT", 0)                              # slot 0: zero first guess and boundary
+            for k in range(n):
+                ens.upload("BC_INIT", rim, first=k)
+            ens.field_save("BC_INIT", 1)                              # slot 1: the rim field (old-diagnose :548)
+        self.stage_timing = {}
+
+    def close(self):
+        self.ens.close()
+
+    def _forcing(self, rhs):
+        ens = self.ens
+        if rhs == 0:
+            ens.forcing_from_B()                                      # f = -rhoB_in (diagnose.f90:2)
+        elif rhs == 1:
+            ens.forcing_thermal()                                     # old-diagnose :383-406
+        else:
+            ens.forcing_zero()                                        # old-diagnose :552
+
+    def step(self, max_iter=100000, r1=1e-8, r2=-1.0, alpha=1.0, on_stage=None):
+        """-> records of this rank's cases, ordered (local timestep, operator, rhs).  on_stage(op, rhs, ens, first) is
+        called after each stage's EE scalars with the first member of kind rhs (tests download fields there); in fused
+        mode once per kind of the stage."""
+        ens = self.ens
+        n = len(self.timesteps)
+        recs = np.zeros(n * CASES_PER_TIMESTEP, X.RECORD_DTYPE)
+
+        def take(rec, op, rhs, first):
+            for k, t in enumerate(self.timesteps):
+                slot = CASES_PER_TIMESTEP * k + 3 * op + rhs
+                recs[slot] = rec[first + k]
+                recs[slot]["case_id"] = CASES_PER_TIMESTEP * t + 3 * op + rhs
+
+        for op in (X.BAROTROPIC, X.BAROCLINIC):
+            ens.assemble(op)
+            if self.fused:
+                for rhs in range(3):
+                    ens.member_window(rhs * n, n)
+                    self._forcing(rhs)
+                ens.member_window()
+                ens.solve(max_iter, r1, r2, alpha)
+                self.stage_timing[(OP_NAMES[op], "all three kinds")] = ens.timing()
+                ens.cal_eta()
+                rec = ens.ee_scalars()
+                for rhs in range(3):
+                    take(rec, op, rhs, rhs * n)
+                    if on_stage is not None:
+                        on_stage(op, rhs, ens, rhs * n)
+            else:
+                for rhs, name in enumerate(RHS_NAMES):
+                    self._forcing(rhs)
+                    ens.field_restore("BC_INIT", 1 if name == "rim_bc" else 0)
+                    ens.solve(max_iter, r1, r2, alpha)
+                    self.stage_timing[(OP_NAMES[op], name)] = ens.timing()
+                    ens.cal_eta()
+                    rec = ens.ee_scalars()
+                    take(rec, op, rhs, 0)
+                    if on_stage is not None:
+                        on_stage(op, rhs, ens, 0)
+        return recs
+
+
 def run(nr, nz, n_timesteps, *, rank=0, world=1, max_iter=100000, r1=1e-8, r2=-1.0, alpha=1.0,
-        domain=(0.0, 1.0, 0.0, 1.0), device=-1, gather_device=None, keep_fields=False):
+        domain=(0.0, 1.0, 0.0, 1.0), device=-1, gather_device=None, keep_fields=False, comm=None, fused=True):
     """Run this rank's block of timesteps; returns (all_records_sorted_by_case_id, local_fields).
     local_fields[(t, op, rhs)] = dict(psi=..., eta=...) only when keep_fields."""
     lo, hi = dp.partition(n_timesteps, world, rank)
-    n_local = hi - lo
-    prof = X.profiles(nr, nz, 0, 0, domain)
-    Q = heating_Q(nr, nz)
-    zero_bc = np.zeros((nz, nr), np.float32)
-    rim = rim_bc(nr, nz)
     fields = {}
-    recs = np.zeros(n_local * CASES_PER_TIMESTEP, X.RECORD_DTYPE)
-    if n_local > 0:
-        with X.Ensemble(nr, nz, n_local, device=device) as ens:
-            ens.set_profiles(prof)
-            for k, t in enumerate(range(lo, hi)):
-                A, B, Cc, _ = ensemble_member(nr, nz, t)
-                ens.upload("A", A, first=k); ens.upload("B", B, first=k); ens.upload("C", Cc, first=k)
-                ens.upload("Q", Q, first=k)
-            for op in (X.BAROTROPIC, X.BAROCLINIC):
-                ens.assemble(op)
-                for rhs, name in enumerate(RHS_NAMES):
-                    if name == "minus_B":
-                        ens.forcing_from_B()
-                    elif name == "thermal":
-                        ens.forcing_thermal()
-                    else:
-                        ens.forcing_zero()
-                    bc = rim if name == "rim_bc" else zero_bc
-                    for k in range(n_local):
-                        ens.upload("BC_INIT", bc, first=k)
-                    ens.solve(max_iter, r1, r2, alpha)
-                    ens.cal_eta()
-                    rec = ens.ee_scalars()
-                    for k, t in enumerate(range(lo, hi)):
-                        cid = CASES_PER_TIMESTEP * t + 3 * op + rhs
-                        slot = CASES_PER_TIMESTEP * k + 3 * op + rhs
-                        recs[slot] = rec[k]
-                        recs[slot]["case_id"] = cid
-                    if keep_fields:
-                        psi, eta = ens.download("PSI"), ens.download("ETA")
-                        for k, t in enumerate(range(lo, hi)):
-                            fields[(t, op, rhs)] = {"psi": psi[k], "eta": eta[k]}
+    recs = np.zeros(0, X.RECORD_DTYPE)
+    if hi > lo:
+        sw = Sweep(nr, nz, range(lo, hi), device=device, domain=domain, fused=fused)
+        try:
+            def keep(op, rhs, ens, first):
+                psi, eta = ens.download("PSI", first, hi - lo), ens.download("ETA", first, hi - lo)
+                for k, t in enumerate(range(lo, hi)):
+                    fields[(t, op, rhs)] = {"psi": psi[k], "eta": eta[k]}
+            recs = sw.step(max_iter, r1, r2, alpha, on_stage=keep if keep_fields else None)
+        finally:
+            sw.close()
     # records are ordered by timestep block, i.e. by case id, on every rank
     per = -(-n_timesteps // world) * CASES_PER_TIMESTEP
     allrec = dp.gather_records(recs, n_timesteps * CASES_PER_TIMESTEP, world, rank, device=gather_device,
-                               per_rank=per) if world > 1 else recs
+                               per_rank=per, comm=comm) if world > 1 else recs
     assert len(allrec) == n_timesteps * CASES_PER_TIMESTEP
     return allrec, fields

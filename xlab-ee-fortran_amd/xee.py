@@ -53,7 +53,8 @@ assert RECORD_DTYPE.itemsize == 128 and C.sizeof(CaseRecord) == 128
 
 class Timing(C.Structure):
     _fields_ = [("solve_ms", C.c_double), ("sweep_ms", C.c_double), ("sweep_launches", C.c_int64),
-                ("iterations", C.c_int64), ("check_launches", C.c_int64), ("redo_tiles", C.c_int64)]
+                ("iterations", C.c_int64), ("check_launches", C.c_int64), ("redo_tiles", C.c_int64),
+                ("redo_tiles_total", C.c_int64), ("inline_redo_tiles", C.c_int64), ("tiles", C.c_int64)]
 
 
 _lib = None
@@ -109,6 +110,9 @@ def lib():
     L.xee_ensemble_forcing_from_B.argtypes = [vp]
     L.xee_ensemble_forcing_thermal.argtypes = [vp]
     L.xee_ensemble_forcing_zero.argtypes = [vp]
+    L.xee_ensemble_member_window.argtypes = [vp, C.c_int, C.c_int]
+    L.xee_ensemble_field_save.argtypes = [vp, C.c_int, C.c_int]
+    L.xee_ensemble_field_restore.argtypes = [vp, C.c_int, C.c_int]
     L.xee_ensemble_assemble.argtypes = [vp, C.c_int]
     L.xee_ensemble_assemble_solver.argtypes = [vp, C.c_int]
     L.xee_legacy_averages.argtypes = [_f32p] * 7 + [C.c_int, C.c_int]
@@ -514,6 +518,17 @@ class Ensemble:
 
     def forcing_zero(self):
         _chk(lib().xee_ensemble_forcing_zero(self._h))
+
+    def member_window(self, first=0, count=0):
+        """forcing_* / field_save / field_restore act on members [first, first+count) only (count 0: all)."""
+        _chk(lib().xee_ensemble_member_window(self._h, first, count))
+
+    def field_save(self, field, slot):
+        """Keep a device-resident copy of `field` (all members) in stash slot `slot` (0..63)."""
+        _chk(lib().xee_ensemble_field_save(self._h, FIELDS[field], slot))
+
+    def field_restore(self, field, slot):
+        _chk(lib().xee_ensemble_field_restore(self._h, FIELDS[field], slot))
 
     def assemble(self, variant):
         _chk(lib().xee_ensemble_assemble(self._h, variant))
