@@ -235,6 +235,24 @@ def test_temporal_blocking_is_bit_identical(T, nr, nz, iters):
     assert got["r1"][0].tobytes() == want["r1"].tobytes() and got["r2"][0].tobytes() == want["r2"].tobytes()
 
 
+@pytest.mark.parametrize("tile", [808, 806, 804])
+@pytest.mark.parametrize("variant", ["BAROTROPIC", "BAROCLINIC"])
+def test_every_tile_shape_is_bit_identical(tile, variant):
+    """option "tile" = waves x rows per lane of the blocked sweep: every instantiated shape, both operator bodies, with a
+    check (a residual-writing launch) inside the run, against the oracle"""
+    nr, nz, iters = 333, 270, 231
+    A, B, Cc, bc = H.rich_inputs(nr, nz, seed=tile)
+    cfg = dict(mode=("DYNAMIC_EFFICIENCY", "CYLINDRICAL", "DENSITY_NORMAL", variant),
+               domain=(0.0, 2.0e5, 0.0, 1.5e4), r1=1e-8, r2=-1.0, max_iter=iters, alpha=1.0)
+    want = H.diagnose_case(A, B, Cc, bc, **cfg)[variant]
+    for T in (8, 11):
+        got = xee.diagnose_case(A, B, Cc, bc, options={"tile": tile, "tb_T": T}, **cfg)[variant]
+        nw, r = divmod(tile, 100)
+        assert got["sweep"]["tile"] == f"64x{nw * r}", got["sweep"]
+        assert biteq(got["psi"][0], want["psi"]) and biteq(got["eta"][0], want["eta"]), (tile, variant, T)
+        assert got["r1"][0].tobytes() == want["r1"].tobytes()
+
+
 def test_single_step_flag_equals_blocked_path():
     nr, nz = 300, 200
     A, B, Cc, bc = H.rich_inputs(nr, nz, seed=77)

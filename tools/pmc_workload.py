@@ -3,7 +3,7 @@ that calibrate FETCH_SIZE for the two load widths used (k_negate: 16 B/lane; k_c
 
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d <dir> -- python3 tools/pmc_workload.py <workload>
 
-workload: ensemble | baroclinic | single | highres   (the shapes of bench.py --workload)
+workload: ensemble | baroclinic | single | highres   (the shapes of bench.py --workload) [iterations [option=value ...]]
 Runs 200 iterations (two blocks of 12 eight-iteration launches plus one residual-writing launch at iterations 100 and 200),
 so every launch is the production kernel on production data; tools/pmc_summarize.py turns the CSVs into
 profiles/<round>/pmc_summary.json and profiles/traffic.json.
@@ -23,9 +23,12 @@ SHAPES = {"ensemble": (1024, 512, 32, 0), "baroclinic": (1024, 512, 32, 1), "sin
 def main():
     wl = sys.argv[1] if len(sys.argv) > 1 else "ensemble"
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+    opts = dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in sys.argv[3:])      # e.g. tile=416 tb_T=10
     nr, nz, M, variant = SHAPES[wl]
     xee = xee_pkg.load()
     with xee.Ensemble(nr, nz, M) as e:
+        for k, v in opts.items():
+            e.set_option(k, v)
         e.set_profiles(xee.profiles(nr, nz))
         for m in range(M):
             A, B, Cc, bc, Q = bench.member_fields(nr, nz, m)

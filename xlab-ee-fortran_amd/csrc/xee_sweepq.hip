@@ -639,14 +639,22 @@ __device__ __forceinline__ TileGeom make_geom(const Grid& g, int T, int bx, int 
     return tg;
 }
 
-// (HIP's second launch bound is waves per SIMD: 4 keeps the kernels at 128 VGPRs, i.e. two workgroups per CU.)
+// (HIP's second launch bound is waves per SIMD: 4 keeps the kernels at 128 VGPRs, 2 at 256, 1 at 512.)
+// Rows per lane decide the register budget: the star keeps 9 values per row (two iterates, five weights, f, y1), the
+// nine-weight body 13.
+template <int NW, int R, bool BARO>
+constexpr int q_waves_per_simd()
+{
+    const int regs = R * (BARO ? 9 : 13);
+    return regs <= 78 ? 4 : (regs <= 208 ? 2 : 1);       // star: R <= 8 | R <= 16(+) ; nine weights: R <= 6 | R <= 16
+}
 // A tile the optimistic body rejects is redone by the exact body: in this same workgroup for the plain variant; the
 // residual-writing variant (one launch per check) only APPENDS the tile to `redo` ([0] = count, then tile numbers) and
 // k_sweep_q_redo, launched right behind it, walks that list -- with both bodies inlined the residual-writing kernel
 // spilled to scratch, and a kernel that uses scratch is throttled at dispatch (158 us for 4 iterations against 105 us
 // for 6 of the plain variant, profiles/r02).
 template <int NW, int R, bool WRITE_R, bool BARO, bool ALPHA1, bool STAMP = false>
-__global__ __launch_bounds__(NW * 64, (BARO || NW * R < 64) ? 4 : 1) void k_sweep_q(Grid g, const float* __restrict__ psi_in,
+__global__ __launch_bounds__(NW * 64, (q_waves_per_simd<NW, R, BARO>())) void k_sweep_q(Grid g, const float* __restrict__ psi_in,
         float* __restrict__ psi_out, const float* __restrict__ base, const float* __restrict__ f,
         float* __restrict__ res, float* __restrict__ snap, const MemberState* __restrict__ st, float alpha, int T, int exact_only,
         int* __restrict__ redo, unsigned long long* __restrict__ stamps, int ntx, int nty, int cnt_slot)
@@ -813,6 +821,12 @@ bool launch_sweep_q(const Grid& g, const float* psi_in, float* psi_out, const fl
     const int exact_only = o.q_exact_only ? 1 : 0;
     // (the nine-weight body needs too many registers at eight rows per lane for two workgroups per CU; at six it fits)
     int cfg = o.tile;
+    // Shapes measured and NOT kept (round 3, profiles/r03/tile_shapes.txt; all bit-identical): 4 waves x 16 rows (the same
+    // 64x64 tile, 256 VGPRs, two workgroups per CU = 2 waves per SIMD) waits less at the barrier (SQ_WAIT_ANY 26 % of the
+    // wave cycles against 38 %) but leaves the VALU idle more often -- with two waves per SIMD a dependent-issue stall is
+    // not covered: 18.3 against 16.9 us per iteration of 32 cases; 8 x 16, 8 x 12, 12 x 8 and 16 x 8 (64x96 / 64x128 tiles,
+    // 66 % instead of 56 % valid points) run ONE workgroup per CU, whose prologue, vote and stores overlap with nothing:
+    // 21-24 us.  The nine-weight body: 4 x 12 28.1, 8 x 12 34.1, 16 x 6 32.3, 8 x 8 36.8 against 27.1 us for 8 x 6.
     if (cfg != 808 && cfg != 806 && cfg != 804) cfg = barotropic ? 808 : 806;
     if ((cfg / 100) * (cfg % 100) - 2 * T < 8) cfg = 808;           // the tile must keep a useful core
     if (desc) { desc->name = barotropic ? "k_sweep_q<star>" : "k_sweep_q<nine>"; desc->T = T; desc->tile_w = 64; desc->tile_h = (cfg / 100) * (cfg % 100); }
