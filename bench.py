@@ -74,6 +74,16 @@ def member_fields(nr, nz, m):
     return one, B.astype(np.float32), one, np.zeros((nz, nr), np.float32), Q.astype(np.float32)
 
 
+def current_build_hash():
+    """tools/build_hash.py: sha256 of the sweep kernel's sources, the driver and the compile flags of THIS tree"""
+    sys.path.insert(0, str(ROOT / "tools"))
+    try:
+        import build_hash
+        return build_hash.build_hash(ROOT)
+    except Exception:
+        return None
+
+
 def traffic_entry(kernel, nr, nz, members, operator):
     """The committed PMC record of the dominant kernel for exactly this workload (profiles/traffic.json, written
     by tools/pmc_summarize.py from the rocprofv3 FETCH_SIZE / WRITE_SIZE / SQ passes, corrections as
@@ -148,7 +158,7 @@ def cpu_baselines(nr, nz, max_iter, sample_iters):
     # aggregate rate from each process's own solve time (process start-up and the one-off input assembly excluded,
     # as in the one-core figure); they ran concurrently, so contention for memory bandwidth is in those times
     agg = sum(r["value"] for r in recs)
-    allc = {"value": agg, "unit": "cases/s", "cores": cores, "kind": one["kind"],
+    allc = {"value": agg, "unit": "cases/s", "cores": cores, "host_nproc": os.cpu_count(), "host_affinity": avail, "kind": one["kind"],
             "sample": f"{cores} concurrent single-core processes, each solve_elliptic on one {nr}x{nz} case for {n_it} iterations "
                       f"(mean {sum(r['ms_per_iteration'] for r in recs) / cores:.2f} ms/iteration per process; {wall:.1f} s wall "
                       f"including start-up), scaled linearly to {max_iter} iterations",
@@ -217,9 +227,12 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # rehearsal of the multi-rank path on a box with fewer GPUs than ranks (never what the driver runs):
-    # XEE_BENCH_BACKEND=gloo XEE_BENCH_DEVICE=0 puts every rank on one card and gathers the records over gloo
-    backend = os.environ.get("XEE_BENCH_BACKEND", "nccl")
+    # torch.distributed carries host-side traffic only -- the 128-byte rendezvous id, the barrier, the max over ranks of
+    # the timing -- so its process group is GLOO: the one RCCL communicator in the process is libxee's own (csrc/xee_comm.hip).
+    # XEE_BENCH_BACKEND=gloo XEE_BENCH_DEVICE=0 is the rehearsal of the multi-rank path on a box with fewer GPUs than ranks
+    # (never what the driver runs): every rank on one card, the records gathered over gloo too (RCCL refuses two ranks on
+    # one device).
+    rehearsal = os.environ.get("XEE_BENCH_BACKEND", "nccl") != "nccl"
     if "XEE_BENCH_DEVICE" in os.environ:
         local_rank = int(os.environ["XEE_BENCH_DEVICE"])
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -229,16 +242,14 @@ def main():
         raise SystemExit("bench.py needs a GPU: libxee has no CPU fallback")
     torch.cuda.set_device(local_rank)
     if world > 1:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-    coll_dev = "cuda" if backend == "nccl" else "cpu"
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
+    coll_dev = "cpu"
 
     nr, nz, M = args.nr, args.nz, args.members
     if args.workload == "sweep":
-        return bench_sweep(args, xee, torch, dist, rank, local_rank, world, backend, coll_dev)
+        return bench_sweep(args, xee, torch, dist, rank, local_rank, world, rehearsal, coll_dev)
     operator = "BAROCLINIC" if args.workload == "baroclinic" else "BAROTROPIC"
     prof = xee.profiles(nr, nz, 0, 0, (0.0, 1.0, 0.0, 1.0))
     ens = xee.Ensemble(nr, nz, M, device=local_rank)
@@ -251,31 +262,7 @@ def main():
 
     from xlab_ee_fortran_amd import ensemble_dp as dp
 
-    # the record gather runs through libxee's own C-ABI communicator (RCCL ncclAllGather); torch.distributed only
-    # carries the 128-byte rendezvous id, the barrier and the max-over-ranks of the timing
-    comm, gather_via = None, "none (1 rank)"
-    if world > 1 and backend == "nccl":
-        def bcast(b):
-            t = torch.zeros(xee.COMM_ID_BYTES, dtype=torch.uint8, device=coll_dev)
-            if rank == 0:
-                t = torch.frombuffer(bytearray(b), dtype=torch.uint8).to(coll_dev)
-            dist.broadcast(t, src=0)
-            return bytes(t.cpu().numpy().tobytes())
-        try:
-            comm = dp.make_comm(xee, world, rank, local_rank, bcast)
-            gather_via = "xee_gather_scalars (RCCL ncclAllGather behind the C-ABI)"
-        except Exception as exc:      # never lose the measurement to the collective's set-up: fall back, and say so
-            comm, gather_via = None, f"torch.distributed all_gather (xee_comm_create failed: {exc})"
-        flags = [None] * world
-        dist.all_gather_object(flags, comm is not None)
-        if not all(flags):
-            if comm is not None:
-                comm.close()
-            comm = None
-            if gather_via.startswith("xee_"):
-                gather_via = "torch.distributed all_gather (another rank could not create its xee_comm)"
-    elif world > 1:
-        gather_via = f"torch.distributed all_gather over {backend} (rehearsal)"
+    comm, gather_via = make_record_comm(xee, dist, rank, local_rank, world, rehearsal)
 
     def step():
         ens.forcing_from_B()                   # A7
@@ -284,7 +271,7 @@ def main():
         ens.cal_eta()                          # K5
         rec = ens.ee_scalars()                 # K8
         if world > 1:                          # the one collective of the path: scalar records over RCCL
-            rec = dp.gather_records(rec, world * M, world, rank, device=coll_dev, comm=comm)
+            rec = dp.gather_records(rec, world * M, world, rank, device=None, comm=comm)
         return rec
 
     def fence():
@@ -322,6 +309,14 @@ def main():
         tflops = FLOP_PER_POINT_ITER * point_iters / sweep_s / 1e12 if sweep_s > 0 else 0.0
         avg_launch_s = sweep_s / max(launches, 1)
         ent = traffic_entry(kernel, nr, nz, M, operator)
+        # the committed counters are quoted only when they were taken on exactly this build of the kernel and driver
+        here = current_build_hash()
+        traffic_source = {"file": "profiles/traffic.json", "entry_found": ent is not None,
+                          "head": ent.get("head") if ent else None, "build_hash": ent.get("build_hash") if ent else None,
+                          "this_build_hash": here,
+                          "matches_build": bool(ent and here and ent.get("build_hash") == here)}
+        if not traffic_source["matches_build"]:
+            ent = None
         traffic = ent["bytes_per_launch"] if ent else None
         b_alg = BYTES_RECOMPUTE[operator]
         hbm = {"algorithmic_bytes_per_point_iter": b_alg,
@@ -335,7 +330,7 @@ def main():
                "note": "temporal blocking: T iterations per pass over the planes, so the effective rates may exceed the HBM peak; "
                        "real_* is measured traffic (PMC) over the launch time"}
         out = {
-            "metric": "diagnosed cases/s (1024x512 r-z grid, SOR to 1e-8)",
+            "metric": "diagnosed cases/s (1024x512 r-z grid, damped Jacobi to max_iter, bit-identical to the reference)",
             "value": cases / dt, "unit": "cases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -362,6 +357,7 @@ def main():
                          "avg_launch_us": avg_launch_s * 1e6, "launches": launches,
                          "point_iterations_per_launch": point_iters / max(launches, 1),
                          "valu_insts_per_launch": ent.get("SQ_INSTS_VALU") if ent else None,
+                         "traffic_source": traffic_source,
                          "hbm": hbm},
         }
         # tie the timed work to a golden (outside the timed region): member 0 of rank 0
@@ -392,7 +388,39 @@ def main():
         dist.destroy_process_group()
 
 
-def bench_sweep(args, xee, torch, dist, rank, local_rank, world, backend, coll_dev):
+def make_record_comm(xee, dist, rank, local_rank, world, rehearsal):
+    """The record gather runs through libxee's own C-ABI communicator (RCCL ncclAllGather).  Ranks first AGREE, over gloo,
+    that each of them can take part (xee_comm_available is not collective) -- only then do they enter the collective
+    xee_comm_create, which gives up after a time-out instead of hanging when a rank never arrives.  Without a communicator
+    the records travel over torch.distributed (gloo), and config.record_gather says so."""
+    from xlab_ee_fortran_amd import ensemble_dp as dp
+    if world == 1:
+        return None, "none (1 rank)"
+    if rehearsal:
+        return None, "torch.distributed all_gather over gloo (rehearsal: every rank on one card)"
+    ok, why = xee.comm_available()
+    flags = [None] * world
+    dist.all_gather_object(flags, (ok, why))
+    if not all(f[0] for f in flags):
+        bad = [(r, f[1]) for r, f in enumerate(flags) if not f[0]]
+        return None, f"torch.distributed all_gather over gloo (no xee_comm: rank(s) {bad} cannot load RCCL / see no device)"
+
+    def bcast(b):
+        box = [b]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+    xee.comm_set_timeout(float(os.environ.get("XEE_COMM_TIMEOUT_S", "180")))
+    try:
+        comm = dp.make_comm(xee, world, rank, local_rank, bcast)
+    except Exception as exc:
+        # a rank that timed out or failed inside the collective cannot be waited for: say why and leave with an error
+        sys.stderr.write(f"[bench rank {rank}] xee_comm_create failed: {exc}\n")
+        sys.stderr.flush()
+        os._exit(3)
+    return comm, f"xee_gather_scalars (RCCL ncclAllGather behind the C-ABI; entry points from {xee.comm_library()})"
+
+
+def bench_sweep(args, xee, torch, dist, rank, local_rank, world, rehearsal, coll_dev):
     """configs[4]: the source-term sweep.  --members timesteps per GPU, six cases per timestep, every input resident
     (xlab-ee-fortran_amd/sweep.py); a step = both operators x three right-hand sides, each stage assemble/forcing ->
     solve -> cal_eta -> EE scalars, then the record gather."""
@@ -400,6 +428,7 @@ def bench_sweep(args, xee, torch, dist, rank, local_rank, world, backend, coll_d
     from xlab_ee_fortran_amd import sweep as S
     nr, nz, nt = args.nr, args.nz, args.members
     sw = S.Sweep(nr, nz, range(rank * nt, (rank + 1) * nt), device=local_rank, fused=not args.sweep_split)
+    comm, gather_via = make_record_comm(xee, dist, rank, local_rank, world, rehearsal)
 
     def keep(op, rhs, ens, first):                 # member 0 of the (BAROTROPIC, -B) kind, for the golden check (device copy)
         if op == 0 and rhs == 0:
@@ -408,8 +437,8 @@ def bench_sweep(args, xee, torch, dist, rank, local_rank, world, backend, coll_d
     def step():
         rec = sw.step(args.max_iter, 1e-8, -1.0, 1.0, on_stage=keep)
         if world > 1:
-            rec = dp.gather_records(rec, world * nt * S.CASES_PER_TIMESTEP, world, rank, device=coll_dev,
-                                    per_rank=nt * S.CASES_PER_TIMESTEP)
+            rec = dp.gather_records(rec, world * nt * S.CASES_PER_TIMESTEP, world, rank, device=None,
+                                    per_rank=nt * S.CASES_PER_TIMESTEP, comm=comm)
         return rec
 
     def fence():
@@ -461,7 +490,7 @@ def bench_sweep(args, xee, torch, dist, rank, local_rank, world, backend, coll_d
                                    f"g0/theta0 d/dr(Q/(Cp exner)), f=0 with chi=1e-5 sin(pi z) on the r=1 rim}} at {nr}x{nz}, "
                                    f"max_iter={args.max_iter}, check every 100 (x8 GPUs x 8 timesteps = the 64 timesteps of configs[4])",
                        "nr": nr, "nz": nz, "timesteps_per_gpu": nt, "cases_per_gpu": nt * S.CASES_PER_TIMESTEP,
-                       "max_iter": args.max_iter, "parallelism": f"ensemble-dp{world}",
+                       "max_iter": args.max_iter, "parallelism": f"ensemble-dp{world}", "record_gather": gather_via,
                        "stages": "six: (operator, kind) one after the other" if args.sweep_split else
                                  "two: per operator, the three kinds of all timesteps in one batch (they share the operator)"},
             "all_cases_ran_to_max_iter": bool(np.all(rec["iters"] == args.max_iter)),
@@ -490,6 +519,8 @@ def bench_sweep(args, xee, torch, dist, rank, local_rank, world, backend, coll_d
         out["check"] = chk
         print(json.dumps(out), flush=True)
     sw.close()
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.destroy_process_group()
 

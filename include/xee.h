@@ -38,6 +38,7 @@ extern "C" {
 #define XEE_ERR_NO_DEVICE         3
 #define XEE_ERR_HIP               4
 #define XEE_ERR_ALLOC             5
+#define XEE_ERR_TIMEOUT           6   /* a collective of the multi-GPU path did not complete in time (a rank is missing) */
 
 /* solver error bitmask, xtt-lib-fortran/elliptic_tools.f90:3-4 */
 #define XEE_ERRBIT_OVER_MAX_ITERATION 1
@@ -363,8 +364,18 @@ typedef struct xee_comm xee_comm_t;
 #define XEE_COMM_ID_BYTES 128
 /* rank 0 makes the rendezvous id and hands its XEE_COMM_ID_BYTES bytes to the other ranks (file, broadcast, ...) */
 int xee_comm_unique_id(char *id);
-/* collective over all ranks: joins the communicator on `device` (-1: the current device) */
+/* NOT collective: can this process take part (librccl loadable, a HIP device visible)?  Hosts agree on this over their own
+ * channel BEFORE anybody enters the collective xee_comm_create -- a rank that failed earlier would leave the others
+ * blocked inside it.  0 = yes, else a status with xee_last_error() set. */
+int xee_comm_available(void);
+/* the file the RCCL entry points were resolved from (dladdr on ncclAllGather), for the record */
+int xee_comm_library(char *path, int path_len);
+/* collective over all ranks: joins the communicator on `device` (-1: the current device).  The rendezvous runs on a helper
+ * thread and is given up after xee_comm_set_timeout's seconds (default 120): XEE_ERR_TIMEOUT instead of a hang when a rank
+ * never arrives (the process should then exit: the helper thread stays blocked inside RCCL). */
 int xee_comm_create(xee_comm_t **comm, const char *id, int rank, int world, int device);
+/* seconds after which xee_comm_create / xee_gather_scalars give up (process-wide; <= 0: wait for ever) */
+int xee_comm_set_timeout(double seconds);
 int xee_comm_rank(const xee_comm_t *comm, int *rank, int *world);
 int xee_comm_destroy(xee_comm_t *comm);
 /* collective: every rank contributes per_rank records (pad a short block with case_id = -1) and receives the

@@ -30,16 +30,34 @@ def test_bench_prints_one_json_line_with_required_keys():
     # (algorithmic, compulsory and measured-traffic rates against the 8 TB/s HBM peak) sits beside it
     assert r["bound"] == "valu" and r["unit"] == "TFLOP/s" and r["peak"] == 78.6 and r["peak_spec"] == 157.3
     assert 0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and "traffic" in r
+    ts = r["traffic_source"]              # (no PMC entry exists for this toy size: nothing may be quoted)
+    assert ts["entry_found"] is False and ts["matches_build"] is False and r["traffic"] is None and len(ts["this_build_hash"]) == 64
     h = r["hbm"]
     assert h["peak_GBps"] == 8000.0 and h["algorithmic_bytes_per_point_iter"] == 20.0 and h["compulsory_GBps"] > 0
     assert h["real_frac_of_peak"] is None or 0 < h["real_frac_of_peak"] <= 1.0
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["value"] > 0 and "sample" in c
     ca = d["cpu_baseline_all_cores"]
-    assert ca["cores"] >= 1 and ca["value"] >= 0.5 * c["value"] and ca["kind"] == c["kind"]
+    assert ca["cores"] >= 1 and ca["value"] >= 0.5 * c["value"] and ca["kind"] == c["kind"] and ca["host_nproc"] >= ca["cores"]
     assert d["all_cases_ran_to_max_iter"] is True and d["value"] > 0
     k = d["check"]
     assert len(k["member0_psi_md5"]) == 32 and len(k["member0_eta_md5"]) == 32 and k["matches_golden"] is None   # (no golden at 128x64)
+
+
+def test_committed_counters_belong_to_this_build():
+    """roofline.traffic / valu_busy_measured come from the rocprofv3 PMC passes committed in profiles/traffic.json; bench.py
+    quotes them only when the sources they were measured on hash like the tree it runs from (tools/build_hash.py) -- and
+    at HEAD they must: a kernel or driver change without a fresh PMC pass would otherwise publish a line without counters."""
+    sys.path.insert(0, str(ROOT / "tools"))
+    import build_hash
+    tj = json.loads((ROOT / "profiles" / "traffic.json").read_text())
+    here = build_hash.build_hash(ROOT)
+    assert tj.get("build_hash") == here, "re-run tools/profile_round.sh + tools/collect_profiles.py: the kernel changed since the PMC passes"
+    assert tj["entries"] and all(e.get("build_hash") == here for e in tj["entries"])
+    sys.path.insert(0, str(ROOT))
+    import bench
+    ent = bench.traffic_entry("k_sweep_q", 1024, 512, 32, "BAROTROPIC")
+    assert ent and ent["bytes_per_launch"] > 3e8 and ent["SQ_ACTIVE_INST_VALU"] > 0
 
 
 def test_bench_gpus2_as_a_plain_command_self_launches():

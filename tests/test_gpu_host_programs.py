@@ -162,6 +162,48 @@ def test_fortran_ensemble_host_equals_single_case_runs(force_gather, tmp_path):
     assert not (tmp_path / ".xee_comm_id").exists()
 
 
+def test_fortran_ensemble_host_two_ranks_on_one_gpu(tmp_path):
+    """Two ranks of bin/xee-ensemble on ONE card (XEE_ENSEMBLE_GATHER=files replaces the RCCL gather, which refuses two
+    ranks on one device): every rank reads the config FILE named on its command line (a launcher forwards stdin to rank 0
+    only), a rendezvous file left behind by a run that died is ignored, each rank writes its own cases' files, rank 0 the
+    summary of all -- same bytes as the one-rank run."""
+    assert ENSEMBLE.exists()
+    nr, nz, N = 80, 56, 5
+    mode = ("DYNAMIC_EFFICIENCY", "CYLINDRICAL", "DENSITY_NORMAL", "BAROTROPIC")
+    cfg = dict(domain=(0.0, 2.0e5, 0.0, 1.5e4), r1=1e-8, r2=-1.0, alpha=1.0, max_iter=300)
+    out = {}
+    for world in (1, 2):
+        base = tmp_path / f"w{world}"; base.mkdir()
+        dirs = []
+        for k in range(N):
+            A, B, Cc, bc = H.rich_inputs(nr, nz, seed=80 + k)
+            d = base / f"case{k}"; d.mkdir()
+            for name, arr in (("A", A), ("B", B), ("C", Cc), ("bc_init", bc)):
+                np.ascontiguousarray(arr, np.float32).tofile(d / f"{name}.bin")
+            dirs.append(d)
+        lines = ["-".join(mode), "%.9e %.9e %.9e %.9e" % cfg["domain"], f"{nr} {nz}",
+                 "%.9e %.9e %d %.9e" % (cfg["r1"], cfg["r2"], cfg["max_iter"], cfg["alpha"]), str(N)] + [str(d) for d in dirs]
+        (base / "ensemble.txt").write_text("\n".join(lines) + "\n")
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "XEE_RANK", "XEE_WORLD")}
+        if world == 2:
+            (base / ".xee_comm_id.job7").write_bytes(b"\0" * 136)        # stale: stamp 0, a dead run's id
+            env.update(XEE_WORLD="2", XEE_LOCAL_RANK="0", XEE_ENSEMBLE_GATHER="files", XEE_JOB_ID="job7", XEE_COMM_TIMEOUT_S="60")
+        procs = []
+        for r in range(world):
+            e = dict(env, XEE_RANK=str(r)) if world == 2 else env
+            procs.append(subprocess.Popen([str(ENSEMBLE), str(base / "ensemble.txt")], cwd=base, stdin=subprocess.DEVNULL,
+                                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=e))
+        for pr in procs:
+            o, _ = pr.communicate(timeout=600)
+            assert pr.returncode == 0, o[-3000:]
+        out[world] = (dirs, [ln for ln in (base / "ensemble_summary.txt").read_text().splitlines() if ln.split() and ln.split()[0].isdigit()])
+        assert not list(base.glob(".xee_comm_id*")), list(base.glob(".xee_comm_id*"))
+    assert out[1][1] == out[2][1] and len(out[2][1]) == N
+    for a, b in zip(out[1][0], out[2][0]):
+        for fn in ("solver_a-sA.bin", "eta-[BAROTROPIC]-A.bin", "rchi-[BAROTROPIC]-O.bin"):
+            assert (a / fn).read_bytes() == (b / fn).read_bytes(), (a, fn)
+
+
 # ---- the legacy program's Fortran host (bin/xee-old-diagnose) -------------------------------------------------------
 
 OLD_HOST = ROOT / "xlab-ee-fortran_amd" / "bin" / "xee-old-diagnose"

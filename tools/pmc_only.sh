@@ -4,6 +4,7 @@ set -e
 tag=$1; shift
 wls=${@:-ensemble}
 root=$(pwd); out=$root/gpurun_out/$tag; mkdir -p $out
+python3 $root/tools/build_hash.py > $out/build_hash.txt
 cd /tmp && export TMPDIR=/tmp
 SQ1="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAIT_ANY"
 SQ2="SQ_WAVES SQ_INSTS_SALU SQ_INSTS_VMEM SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_BUSY_CU_CYCLES"

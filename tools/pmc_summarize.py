@@ -117,12 +117,26 @@ def main():
             entries.append({k: rec[k] for k in ("workload", "short", "kernel", "nr", "nz", "members", "operator", "FETCH_SIZE_kib",
                                                 "WRITE_SIZE_kib", "fetch_correction", "bytes_per_launch")}
                            | {c: rec[c] for c in rec if c.startswith("SQ_") or c.startswith("TCC_")})
+    # provenance: the hash of the kernel sources the passes ran on (written on the GPU box by profile_round.sh /
+    # pmc_only.sh) and the git HEAD at summary time -- bench.py quotes an entry only if its own sources hash the same
+    bh = (src / "build_hash.txt").read_text().strip() if (src / "build_hash.txt").exists() else None
+    try:
+        import subprocess
+        head = subprocess.run(["git", "rev-parse", "HEAD"], capture_output=True, text=True, cwd=Path(__file__).parent).stdout.strip() or None
+        dirty = bool(subprocess.run(["git", "status", "--porcelain", "--", "xlab-ee-fortran_amd/csrc", "xlab-ee-fortran_amd/Makefile"],
+                                    capture_output=True, text=True, cwd=Path(__file__).parent.parent).stdout.strip())
+    except OSError:
+        head, dirty = None, None
+    for e_ in entries:
+        e_["build_hash"] = bh
+        e_["head"] = head
+        e_["head_dirty"] = dirty
     (dst / "pmc_summary.json").write_text(json.dumps(summary, indent=1) + "\n")
     if entries:
         tj = dst.parent / "traffic.json"
         (tj).write_text(json.dumps({"_comment": "per-launch HBM bytes and SQ counters of the dominant sweep kernel, from the rocprofv3 PMC passes "
                                     f"summarised in {dst.name}/pmc_summary.json (tools/pmc_summarize.py); bench.py quotes the entry of its workload",
-                                    "round": dst.name, "entries": entries}, indent=1) + "\n")
+                                    "round": dst.name, "build_hash": bh, "head": head, "entries": entries}, indent=1) + "\n")
     print(json.dumps(summary, indent=1))
 
 

@@ -12,6 +12,7 @@ root=$(pwd)
 out=$root/gpurun_out/$tag
 rm -rf $out/stats $out/pmc $out/summary
 mkdir -p $out
+python3 $root/tools/build_hash.py > $out/build_hash.txt
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $root/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $out/bench_under_rocprof.json 2> $out/bench_under_rocprof.err
 echo "stats done"

@@ -13,8 +13,14 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -55,6 +61,8 @@ int need_rccl()
     return XEE_OK;
 }
 
+std::atomic<double> g_timeout_s{120.0};
+
 int nccl_fail(const char* what, ncclResult_t r)
 {
     const std::string msg = std::string(what) + ": " + rccl().GetErrorString(r);
@@ -87,6 +95,30 @@ int xee_comm_unique_id(char* id /* XEE_COMM_ID_BYTES */)
     return XEE_OK;
 }
 
+int xee_comm_available(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return xee::record_failure(XEE_ERR_NO_DEVICE, "no HIP device visible");
+    return need_rccl();
+}
+
+int xee_comm_library(char* path, int path_len)
+{
+    if (!path || path_len < 2) return xee::record_failure(XEE_ERR_INVALID_ARGUMENT, "xee_comm_library: bad buffer");
+    if (int s = need_rccl()) return s;
+    Dl_info info;
+    const char* name = (dladdr(reinterpret_cast<void*>(rccl().AllGather), &info) && info.dli_fname) ? info.dli_fname : "?";
+    strncpy(path, name, (size_t)path_len - 1);
+    path[path_len - 1] = 0;
+    return XEE_OK;
+}
+
+int xee_comm_set_timeout(double seconds)
+{
+    g_timeout_s.store(seconds);
+    return XEE_OK;
+}
+
 int xee_comm_create(xee_comm_t** out, const char* id, int rank, int world, int device)
 {
     if (!out || !id || world < 1 || rank < 0 || rank >= world) return xee::record_failure(XEE_ERR_INVALID_ARGUMENT, "xee_comm_create: bad argument");
@@ -100,7 +132,30 @@ int xee_comm_create(xee_comm_t** out, const char* id, int rank, int world, int d
     c->rank = rank; c->world = world; c->device = device;
     ncclUniqueId u;
     memcpy(&u, id, sizeof u);
-    const ncclResult_t r = rccl().CommInitRank(&c->comm, world, u, rank);
+    // ncclCommInitRank blocks until every rank has arrived, for ever if one never does: it runs on a helper thread and
+    // this one waits with a deadline (the job is shared so that a late helper never touches freed memory)
+    struct Job { std::mutex m; std::condition_variable cv; bool done = false; ncclResult_t r = ncclSuccess; ncclComm_t comm = nullptr; };
+    auto job = std::make_shared<Job>();
+    std::thread([job, u, world, rank, device] {
+        ncclComm_t cm = nullptr;
+        ncclResult_t r = ncclSystemError;
+        if (hipSetDevice(device) == hipSuccess) r = rccl().CommInitRank(&cm, world, u, rank);
+        std::lock_guard<std::mutex> lk(job->m);
+        job->r = r; job->comm = cm; job->done = true;
+        job->cv.notify_all();
+    }).detach();
+    {
+        std::unique_lock<std::mutex> lk(job->m);
+        const double to = g_timeout_s.load();
+        if (to > 0) {
+            if (!job->cv.wait_for(lk, std::chrono::duration<double>(to), [&] { return job->done; })) {
+                delete c;
+                return xee::record_failure(XEE_ERR_TIMEOUT, "ncclCommInitRank: not every rank arrived before the time-out (xee_comm_set_timeout)");
+            }
+        } else job->cv.wait(lk, [&] { return job->done; });
+    }
+    const ncclResult_t r = job->r;
+    c->comm = job->comm;
     if (r != ncclSuccess) { delete c; return nccl_fail("ncclCommInitRank", r); }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rccl().CommDestroy(c->comm); delete c; return xee::record_failure(XEE_ERR_HIP, "hipStreamCreate failed"); }
     *out = c;
@@ -141,7 +196,17 @@ int xee_gather_scalars(xee_comm_t* c, const xee_case_record_t* local, int per_ra
     const ncclResult_t r = rccl().AllGather(c->send, c->recv, (size_t)per_rank * 32, ncclInt32, c->comm, c->stream);
     if (r != ncclSuccess) return nccl_fail("ncclAllGather", r);
     if (hipMemcpyAsync(all, c->recv, bytes * c->world, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return xee::record_failure(XEE_ERR_HIP, "gather D2H failed");
-    if (hipStreamSynchronize(c->stream) != hipSuccess) return xee::record_failure(XEE_ERR_HIP, "gather stream sync failed");
+    // (polled with a deadline: a rank that died before the collective would otherwise hang the others here)
+    const double to = g_timeout_s.load();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipStreamQuery(c->stream);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) return xee::record_failure(XEE_ERR_HIP, "gather stream failed");
+        if (to > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > to)
+            return xee::record_failure(XEE_ERR_TIMEOUT, "ncclAllGather: not every rank arrived before the time-out (xee_comm_set_timeout)");
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
     return XEE_OK;
 }
 

@@ -234,6 +234,12 @@ interface
         integer(c_int) :: st
     end function
 
+    function xee_comm_set_timeout(seconds) bind(C, name="xee_comm_set_timeout") result(st)
+        import :: c_int, c_double
+        real(c_double), value :: seconds
+        integer(c_int) :: st
+    end function
+
     function xee_comm_destroy(comm) bind(C, name="xee_comm_destroy") result(st)
         import :: c_int, c_ptr
         type(c_ptr), value :: comm

@@ -1,4 +1,4 @@
-! xee_ensemble.f90 -- Fortran 2008 ENSEMBLE host of the MI355X path: `xee-ensemble < ensemble.txt`, one process per GPU.
+! xee_ensemble.f90 -- Fortran 2008 ENSEMBLE host of the MI355X path: `xee-ensemble ensemble.txt`, one process per GPU.
 !
 ! The reference diagnoses one case per run (src/diagnose/main.f90); the per-run solves of src/diagnose/diagnose.f90:4-55
 ! are independent between runs, so an ensemble of cases that share one grid and one mode line is partitioned in
@@ -7,7 +7,9 @@
 ! writes its cases' output files exactly as xee-diagnose would, and the 128-byte case records are all-gathered over
 ! RCCL through libxee's C-ABI (xee_gather_scalars); rank 0 writes ensemble_summary.txt.
 !
-! Config (stdin; the reference's line reader: // comments, blank lines skipped):
+! Config: the file named by the first command-line argument, else by XEE_CONFIG, else stdin (a launcher such as Open MPI
+! forwards stdin to rank 0 ONLY: with more than one rank give the file by name).  The reference's line reader: // comments,
+! blank lines skipped:
 !     TYPE-GEOMETRY-DENSITY-OPERATOR           as diag.txt line 1 (read-input.f90:2-51); TYPE in DYNAMIC_EFFICIENCY | NONE
 !     Lr1 Lr2 Lz1 Lz2 | planet_radius Lz1 Lz2  (read-input.f90:55-76)
 !     nr nz
@@ -15,8 +17,13 @@
 !     n_cases
 !     <case directory> x n_cases               each holds A.bin B.bin C.bin bc_init.bin [Q.bin]; outputs go there too
 ! Ranks: XEE_RANK / XEE_WORLD (else OMPI_COMM_WORLD_RANK/SIZE, else RANK/WORLD_SIZE; default 0/1), device = XEE_LOCAL_RANK
-! (else LOCAL_RANK, else rank).  Rendezvous: rank 0 writes the 128-byte RCCL id to <first case directory>/../.xee_comm_id
-! (override: XEE_COMM_FILE), the others wait for it.
+! (else LOCAL_RANK, else rank).  Rendezvous: rank 0 writes a time stamp and the 128-byte RCCL id to
+! <first case directory>/../.xee_comm_id[.<job>] (override: XEE_COMM_FILE; <job> = XEE_JOB_ID, else the launcher's
+! OMPI_MCA_ess_base_jobid / SLURM_JOB_ID / TORCHELASTIC_RUN_ID when set), the others wait for a file whose stamp is not
+! older than their own start (a file left behind by a run that died is ignored, not joined), and xee_comm_create itself
+! gives up after a time-out (XEE_COMM_TIMEOUT_S, default 120) instead of hanging when a rank never arrives.
+! XEE_ENSEMBLE_GATHER=files replaces the RCCL gather by per-rank record files next to the rendezvous file: the rehearsal of
+! the multi-rank path on ONE GPU (RCCL refuses two ranks on one device).
 program xee_ensemble
 use, intrinsic :: iso_c_binding
 use xee_c_api
@@ -25,8 +32,11 @@ use read_input_tools
 use message_tools
 implicit none
 
-integer, parameter :: stdin = 5
-character(256) :: mode_str, word(4), buffer, comm_file
+integer :: stdin = 5
+character(256) :: mode_str, word(4), buffer, comm_file, job_id, rec_file
+integer(8) :: t_start, t_file
+real(8) :: comm_timeout
+logical :: gather_by_files
 character(256), allocatable :: case_dir(:)
 integer :: nr, nz, geometry, density_mode, operator_complexity, n_cases, rank, world, device, lo, hi, per, n_local
 integer :: i, k, m, saved_max_iter, ndev, variant, nvariants, variants(2), ios
@@ -45,6 +55,19 @@ character(64) :: val
 call env_int("XEE_RANK", "OMPI_COMM_WORLD_RANK", "RANK", 0, rank)
 call env_int("XEE_WORLD", "OMPI_COMM_WORLD_SIZE", "WORLD_SIZE", 1, world)
 call env_int("XEE_LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "LOCAL_RANK", rank, device)
+
+t_start = wall_seconds()
+call get_command_argument(1, buffer, status=ios)                          ! the config: argument 1, XEE_CONFIG, or stdin
+if (ios /= 0 .or. len_trim(buffer) == 0) call get_environment_variable("XEE_CONFIG", buffer, status=ios)
+if (ios == 0 .and. len_trim(buffer) > 0) then
+    open (newunit=stdin, file=trim(buffer), action="read", status="old", iostat=ios)
+    if (ios /= 0) then
+        call error_msg("INIT", 1, "cannot open the config file " // trim(buffer)); error stop 1
+    end if
+else if (world > 1 .and. rank > 0) then
+    print *, "xee-ensemble: rank ", rank, " reads its config from stdin -- most launchers forward stdin to rank 0 only;"
+    print *, "              name the file as the first argument (or XEE_CONFIG) instead."
+end if
 
 call read_input(stdin, mode_str)
 do i = 1, size(word)
@@ -107,30 +130,52 @@ end if
 device = mod(device, ndev)
 
 comm = c_null_ptr
+gather_by_files = .false.
 if (world > 1 .or. env_set("XEE_ENSEMBLE_FORCE_GATHER")) then          ! the collective's rendezvous
     call get_environment_variable("XEE_COMM_FILE", comm_file, status=ios)
-    if (ios /= 0 .or. len_trim(comm_file) == 0) comm_file = trim(case_dir(1)) // "/../.xee_comm_id"
+    if (ios /= 0 .or. len_trim(comm_file) == 0) then
+        comm_file = trim(case_dir(1)) // "/../.xee_comm_id"
+        call first_env(["XEE_JOB_ID              ", "OMPI_MCA_ess_base_jobid ", "SLURM_JOB_ID            ", "TORCHELASTIC_RUN_ID     "], job_id)
+        if (len_trim(job_id) > 0) comm_file = trim(comm_file) // "." // trim(job_id)
+    end if
+    call get_environment_variable("XEE_ENSEMBLE_GATHER", buffer, status=ios)
+    gather_by_files = ios == 0 .and. trim(buffer) == "files"
+    comm_timeout = 120.0d0
+    call get_environment_variable("XEE_COMM_TIMEOUT_S", buffer, status=ios)
+    if (ios == 0 .and. len_trim(buffer) > 0) read (buffer, *, iostat=ios) comm_timeout
+    call xee_check(xee_comm_set_timeout(comm_timeout), "comm_set_timeout")
     if (rank == 0) then
-        call xee_check(xee_comm_unique_id(comm_id), "comm_unique_id")
+        comm_id = c_null_char
+        if (.not. gather_by_files) call xee_check(xee_comm_unique_id(comm_id), "comm_unique_id")
         open (unit=17, file=trim(comm_file)//".tmp", access="stream", form="unformatted", status="replace")
-        write (17) comm_id
+        write (17) wall_seconds(), comm_id
         close (17)
-        call execute_command_line("mv '" // trim(comm_file) // ".tmp' '" // trim(comm_file) // "'")
+        call execute_command_line("mv -f '" // trim(comm_file) // ".tmp' '" // trim(comm_file) // "'")
     else
-        do i = 1, 6000                                                    ! up to 10 minutes
+        file_exists = .false.
+        do i = 1, int(comm_timeout * 10.0d0) + 1
             inquire(file=trim(comm_file), exist=file_exists)
-            if (file_exists) exit
+            if (file_exists) then
+                ! a file from THIS launch carries a stamp no older than this rank's own start (a few seconds of slack for
+                ! start-up skew); anything older was left behind by a run that died: keep waiting for rank 0 to replace it
+                open (unit=17, file=trim(comm_file), access="stream", form="unformatted", status="old", iostat=ios)
+                if (ios == 0) then
+                    read (17, iostat=ios) t_file, comm_id
+                    close (17)
+                end if
+                file_exists = ios == 0 .and. t_file >= t_start - 5
+                if (file_exists) exit
+            end if
             call execute_command_line("sleep 0.1")
         end do
         if (.not. file_exists) then
-            call error_msg("INIT", 1, "rank 0 never wrote " // trim(comm_file)); error stop 1
+            call error_msg("INIT", 1, "rank 0 never wrote a fresh " // trim(comm_file)); error stop 1
         end if
-        open (unit=17, file=trim(comm_file), access="stream", form="unformatted", status="old")
-        read (17) comm_id
-        close (17)
     end if
-    call xee_check(xee_comm_create(comm, comm_id, rank, world, device), "comm_create")
-    if (rank == 0) call execute_command_line("rm -f '" // trim(comm_file) // "'")     ! (everyone has joined: create is collective)
+    if (.not. gather_by_files) then
+        call xee_check(xee_comm_create(comm, comm_id, rank, world, device), "comm_create")
+        if (rank == 0) call execute_command_line("rm -f '" // trim(comm_file) // "'")     ! (everyone has joined: create is collective)
+    end if
 end if
 
 allocate(mine(per), everyone(per * world))
@@ -213,6 +258,31 @@ call system_clock(clk1)
 if (c_associated(comm)) then
     call xee_check(xee_gather_scalars(comm, mine, per, everyone), "gather_scalars")
     call xee_check(xee_comm_destroy(comm), "comm_destroy")
+else if (gather_by_files) then                       ! rehearsal on one GPU: the same records, through the file system
+    write (rec_file, '(A,A,I0)') trim(comm_file), ".rec", rank
+    open (unit=17, file=trim(rec_file)//".tmp", access="stream", form="unformatted", status="replace")
+    write (17) mine
+    close (17)
+    call execute_command_line("mv -f '" // trim(rec_file) // ".tmp' '" // trim(rec_file) // "'")
+    if (rank == 0) then
+        do k = 0, world - 1
+            write (rec_file, '(A,A,I0)') trim(comm_file), ".rec", k
+            file_exists = .false.
+            do i = 1, int(comm_timeout * 10.0d0) + 1
+                inquire(file=trim(rec_file), exist=file_exists)
+                if (file_exists) exit
+                call execute_command_line("sleep 0.1")
+            end do
+            if (.not. file_exists) then
+                call error_msg("GATHER", 1, "no records from rank: " // trim(rec_file)); error stop 1
+            end if
+            open (unit=17, file=trim(rec_file), access="stream", form="unformatted", status="old")
+            read (17) everyone(k*per+1:(k+1)*per)
+            close (17)
+            call execute_command_line("rm -f '" // trim(rec_file) // "'")
+        end do
+        call execute_command_line("rm -f '" // trim(comm_file) // "'")
+    end if
 else
     everyone(1:per) = mine(1:per)
 end if
@@ -247,6 +317,32 @@ subroutine env_int(n1, n2, n3, default, v)
         read (val, *, iostat=io) v
         if (io /= 0) v = default
     end if
+end subroutine
+
+! seconds since 2000-01-01 (local time; the ranks of one node share a clock)
+integer(8) function wall_seconds()
+    integer :: v(8), y, mth, d
+    integer(8) :: days
+    call date_and_time(values=v)
+    y = v(1); mth = v(2); d = v(3)
+    if (mth <= 2) then
+        y = y - 1; mth = mth + 12
+    end if
+    days = 365_8 * y + y / 4 - y / 100 + y / 400 + (153 * (mth - 3) + 2) / 5 + d - 730426_8
+    wall_seconds = days * 86400_8 + v(5) * 3600_8 + v(6) * 60_8 + v(7)
+end function
+
+! the first of the named environment variables that is set and not blank ('' if none)
+subroutine first_env(names, value)
+    character(*), intent(in) :: names(:)
+    character(*), intent(out) :: value
+    integer :: status, n
+    value = ''
+    do n = 1, size(names)
+        call get_environment_variable(trim(names(n)), value, status=status)
+        if (status == 0 .and. len_trim(value) > 0) return
+        value = ''
+    end do
 end subroutine
 
 logical function env_set(name)

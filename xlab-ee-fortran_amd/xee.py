@@ -13,7 +13,7 @@ import numpy as np
 
 _HERE = Path(__file__).resolve().parent
 
-__all__ = ["Ensemble", "Comm", "comm_unique_id", "COMM_ID_BYTES", "XeeError", "lib", "lib_path", "device_count", "set_default_option", "reset_default_options", "last_sweep_info", "tier1_release",
+__all__ = ["Ensemble", "Comm", "comm_unique_id", "comm_available", "comm_library", "comm_set_timeout", "COMM_ID_BYTES", "XeeError", "lib", "lib_path", "device_count", "set_default_option", "reset_default_options", "last_sweep_info", "tier1_release",
            "profiles", "cal_coe", "do_elliptic", "solve_elliptic", "solver_coefficients", "residual_norm", "cal_eta", "cal_uw",
            "integrate_weight_B", "cal_sum_Qeta", "cal_wtheta", "rhs_thermal", "rhs_from_B", "rhs_momentum", "fd_stencil",
            "exchange_conversion", "legacy_averages", "JJ_B", "add_fields", "diagnose_case", "CaseRecord", "RECORD_DTYPE", "Timing", "FIELDS", "FD_STENCILS",
@@ -132,6 +132,8 @@ def lib():
     L.xee_theta_anomaly_update.argtypes = [_f32p, C.c_float, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p,
                                            C.c_int, C.c_int]
     L.xee_comm_unique_id.argtypes = [C.c_char_p]
+    L.xee_comm_library.argtypes = [C.c_char_p, C.c_int]
+    L.xee_comm_set_timeout.argtypes = [C.c_double]
     L.xee_comm_create.argtypes = [C.POINTER(vp), C.c_char_p, C.c_int, C.c_int, C.c_int]
     L.xee_comm_destroy.argtypes = [vp]
     L.xee_gather_scalars.argtypes = [vp, C.c_void_p, C.c_int, C.c_void_p]
@@ -404,6 +406,23 @@ def comm_unique_id():
     buf = C.create_string_buffer(COMM_ID_BYTES)
     _chk(lib().xee_comm_unique_id(buf))
     return buf.raw
+
+
+def comm_available():
+    """-> (ok, reason): can this process join a communicator (librccl loadable, a device visible)?  Not collective."""
+    st = lib().xee_comm_available()
+    return st == 0, ("" if st == 0 else (lib().xee_last_error() or b"").decode())
+
+
+def comm_library():
+    """the file the RCCL entry points were resolved from"""
+    buf = C.create_string_buffer(512)
+    _chk(lib().xee_comm_library(buf, 512))
+    return buf.value.decode()
+
+
+def comm_set_timeout(seconds):
+    _chk(lib().xee_comm_set_timeout(float(seconds)))
 
 
 class Comm:
