@@ -112,3 +112,20 @@ def test_cabi_record_gather_on_one_rank():
     out = comm.gather(rec, 8)
     assert len(out) == 8 and out[:5].tobytes() == rec.tobytes() and np.all(out["case_id"][5:] == -1)
     comm.close()
+
+
+def test_comm_create_gives_up_when_a_rank_never_arrives():
+    """xee_comm_create is collective; a rank that never arrives must not hang the others for ever: rank 0 of a world of two,
+    alone, gets XEE_ERR_TIMEOUT after xee_comm_set_timeout's seconds (in a child process: the helper thread stays inside RCCL)."""
+    code = ("import os, sys, time; sys.path.insert(0, %r); import xee_pkg; xee = xee_pkg.load();\n"
+            "ok, why = xee.comm_available(); assert ok, why\n"
+            "print('LIB', xee.comm_library()); xee.comm_set_timeout(4.0); t0 = time.time()\n"
+            "try:\n"
+            "    xee.Comm(xee.comm_unique_id(), 0, 2)\n"
+            "    print('JOINED?')\n"
+            "except xee.XeeError as e:\n"
+            "    print('STATUS', e.status, round(time.time() - t0)); sys.stdout.flush()\n"
+            "os._exit(0)\n" % str(ROOT))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "STATUS 6" in p.stdout, p.stdout + p.stderr[-2000:]
+    assert "librccl" in p.stdout
