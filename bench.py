@@ -472,8 +472,8 @@ def bench_sweep(args, xee, torch, dist, rank, local_rank, world, rehearsal, coll
             sweep_s = a["sweep_ms"] * 1e-3
             kinds[f"{opn}/{rhsn}"] = {
                 "avg_launch_us": sweep_s / max(a["sweep_launches"], 1) * 1e6,
-                "redo_tile_fraction": (a["redo_tiles_total"] + a["inline_redo_tiles"]) / max(a["tiles"], 1),
-                "redo_tiles": a["redo_tiles_total"], "inline_redo_tiles": a["inline_redo_tiles"], "tiles": a["tiles"],
+                "redo_tile_fraction": (a["redo_tiles"] + a["inline_redo_tiles"]) / max(a["tiles"], 1),
+                "redo_tiles": a["redo_tiles"], "inline_redo_tiles": a["inline_redo_tiles"], "tiles": a["tiles"],
                 "solve_ms_per_stage": a["solve_ms"] / args.steps,
                 "cases_per_s_of_this_stage": nm * args.steps / (a["solve_ms"] * 1e-3) if a["solve_ms"] > 0 else None,
                 "TFLOPs": FLOP_PER_POINT_ITER * interior * nm * a["iterations"] / sweep_s / 1e12 if sweep_s > 0 else None}

@@ -106,6 +106,9 @@ int xee_last_sweep_info(char *name, int name_len, int *T, int *tile_w, int *tile
  * the copy of this thread's last xee_cal_coe; this call frees both (the next Tier-1 call simply builds them again).
  * A call that fails drops the cached ensemble by itself. */
 int xee_tier1_release(void);
+/* test aid: out[0] device ensembles created so far in this process, out[1] device staging buffers the Tier-1 entry points
+ * allocated, out[2] Tier-1 caches released because their thread ended, out[3] reserved */
+int xee_debug_counters(int64_t *out /* 4 */);
 
 /* replaces the residual norm inside solve_elliptic, elliptic_tools.f90:193-199, as a stand-alone call:
  * *sum_sq = the sequential fp32 sum (i outer, j inner) of res(i,j)**2 over the interior, bit for bit;
@@ -268,14 +271,12 @@ typedef struct {
     int64_t sweep_launches; /* number of sweep kernel launches in the last solve */
     int64_t iterations;     /* Jacobi iterations enqueued in the last solve (per member) */
     int64_t check_launches; /* residual-norm / state-machine launches */
-    int64_t redo_tiles;     /* tiles the LAST residual-writing sweep launch left to the exact body (k_sweep_q's optimistic
-                               body rejected them: zero residuals, non-finite iterates, exotic coefficients); 0 on the
-                               common path -- a diagnostic of how often the fallback runs */
-    int64_t redo_tiles_total;  /* ... summed over ALL residual-writing launches of the last solve */
-    int64_t inline_redo_tiles; /* tiles the plain (not residual-writing) launches redid with the exact body inside their own
-                                  workgroup, summed over the last solve */
+    int64_t redo_tiles;        /* tiles of the last solve that the blocked sweep's optimistic body rejected (non-finite iterates,
+                                  values outside the range of its strength-reduced division, -0 iterates, exotic coefficients)
+                                  and the exact body recomputed in the same workgroup: in residual-writing launches ... */
+    int64_t inline_redo_tiles; /* ... and in the plain launches; 0 on the common path */
     int64_t tiles;             /* tile executions of the blocked sweep in the last solve (launches x tiles per launch):
-                                  (redo_tiles_total + inline_redo_tiles) / tiles = the fraction that took the exact body */
+                                  (redo_tiles + inline_redo_tiles) / tiles = the fraction that took the exact body */
 } xee_timing_t;
 
 /* flags of xee_ensemble_solve */

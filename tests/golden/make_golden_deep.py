@@ -11,6 +11,7 @@ golden_hashes.json next to the anchors of make_golden.py.
   * member{m}_1024x512_600[_baroclinic]              -- noisy members (m>0) at full size for the batched-vs-
     reference test (tests/test_gpu_fullsize.py).
   * m1024x512_baroclinic_2000                         -- full-B operator anchor at moderate depth.
+  * member{m}_1024x512_200                            -- anchors for the whole 256-member batch of configs[2].
 
 One reference process per case (the reference is single-threaded): ~40-50 min per 100,000-iteration case.
 Usage: python tests/golden/make_golden_deep.py [--jobs 4] [--only name,name]
@@ -41,6 +42,8 @@ def cases():
         c[f"member{m}_1024x512_600"] = ("member", m, BT, 600)
     for m in (1, 6):
         c[f"member{m}_1024x512_600_baroclinic"] = ("member", m, BC, 600)
+    for m in (1, 2, 3, 7, 255):          # the 256-member ensemble of configs[2] in ONE batch (tests/test_gpu_fullsize.py)
+        c[f"member{m}_1024x512_200"] = ("member", m, BT, 200)
     # the highres workload of bench.py (configs[3]): member 0 at 4096x2048, 2,000 iterations (~25 min of the reference)
     c["bench_m0_4096x2048_2000"] = ("member4096", 0, BT, 2000)
     return c

@@ -82,3 +82,39 @@ def test_full_size_batch_members(variant, M, ref_members, golden_hashes):
     m = M - 1
     want = H.diagnose_case(A[m], B[m], Cc[m], bc[m], **cfg)[variant]
     assert biteq(out["psi"][m], want["psi"]) and out["r1"][m].tobytes() == want["r1"].tobytes()
+
+
+def test_the_256_member_ensemble_of_configs2_in_one_batch(golden_hashes):
+    """BASELINE.json configs[2] whole: 256 members x 1024x512 resident in ONE device ensemble (6.7 GB of planes), 200
+    iterations.  Members the reference program was run on against its md5s, every other member against the same member
+    solved alone."""
+    M, nr, nz, iters = 256, 1024, 512, 200
+    prof = xee.profiles(nr, nz)
+    refs = [m for m in (1, 2, 3, 7, 255) if f"member{m}_1024x512_{iters}" in golden_hashes]
+    assert len(refs) == 5, "reference anchors missing: tests/golden/make_golden_deep.py --only member1_1024x512_200,..."
+    with xee.Ensemble(nr, nz, M) as big, xee.Ensemble(nr, nz, 1) as one:
+        big.set_profiles(prof); one.set_profiles(prof)
+        for m in range(M):
+            A, B, Cc, bc = H.member_inputs(nr, nz, m)
+            for name, arr in (("A", A), ("B", B), ("C", Cc), ("BC_INIT", bc)):
+                big.upload(name, arr, first=m)
+        big.forcing_from_B(); big.assemble(xee.BAROTROPIC)
+        rec = big.solve(iters, 1e-8, -1.0, 1.0)
+        big.cal_eta()
+        assert np.all(rec["iters"] == iters) and big.sweep_info()["kernel"] == "k_sweep_q"
+        for m in range(M):
+            psi, eta = big.download("PSI", m, 1)[0], big.download("ETA", m, 1)[0]
+            if m in refs:
+                g = golden_hashes[f"member{m}_1024x512_{iters}"]
+                assert H.md5(psi) == g["md5"]["rchi-[BAROTROPIC]-O.bin"], m
+                assert H.md5(eta) == g["md5"]["eta-[BAROTROPIC]-A.bin"], m
+                assert np.isclose(float(rec["err_now"][m]), float(g["relax"][0][1]), rtol=2e-7, atol=0)
+            else:
+                A, B, Cc, bc = H.member_inputs(nr, nz, m)
+                for name, arr in (("A", A), ("B", B), ("C", Cc), ("BC_INIT", bc)):
+                    one.upload(name, arr)
+                one.forcing_from_B(); one.assemble(xee.BAROTROPIC)
+                r1 = one.solve(iters, 1e-8, -1.0, 1.0)
+                one.cal_eta()
+                assert biteq(psi, one.download("PSI")[0]) and biteq(eta, one.download("ETA")[0]), m
+                assert rec["err_now"][m].tobytes() == r1["err_now"][0].tobytes(), m

@@ -42,6 +42,45 @@ def test_pipelined_equals_synchronous_and_oracle(max_iter):
         assert len(set(int(v) for v in a["iters"])) > 1 and int(a["iters"].max()) < max_iter
 
 
+@pytest.mark.parametrize("max_iter", [6400, 6437, 6600, 7057, 20000])
+def test_graphed_small_batch_driver(max_iter):
+    """Small batches with a long solve ahead run up to EIGHT check blocks per graph over a ring of 3 x 8 slots (solve_graphed).
+    Members that stop at every slot index of the ring (and while later blocks of their graph are already enqueued), caps
+    on and off a check boundary, check counts that are not a multiple of four: same bits as the one-block-at-a-time
+    driver (option graph_blocks = 0), the synchronous driver and the oracle; XEE_F_RESIDUAL = each member's last check."""
+    nr, nz, M = 96, 64, 12
+    ins = [H.member_inputs(nr, nz, m) for m in range(M)]
+    A, B, Cc, bc = (np.stack([x[k] for x in ins]) for k in range(4))
+    # per-member tolerances cannot be set, so members differ by their inputs; r1 chosen so that stops spread over many checks
+    cfg = dict(r1=1.5e-4, r2=4e-3, max_iter=max_iter, alpha=1.0)
+    outs = {}
+    for tag, opts in (("graphed", {}), ("graphed4e", {"graph_blocks": 4, "graph_events": 1}), ("graphed2", {"graph_blocks": 2}),
+                      ("single", {"graph_blocks": 0}), ("sync", {"sync_checks": 1})):
+        with xee.Ensemble(nr, nz, M) as e:
+            for kk, v in opts.items():
+                e.set_option(kk, v)
+            e.set_profiles(xee.profiles(nr, nz))
+            for name, arr in (("A", A), ("B", B), ("C", Cc), ("BC_INIT", bc)):
+                e.upload(name, arr)
+            e.forcing_from_B(); e.assemble(xee.BAROTROPIC)
+            rec = e.solve(cfg["max_iter"], cfg["r1"], cfg["r2"], cfg["alpha"])
+            outs[tag] = (rec.copy(), e.download("PSI"), e.download("RESIDUAL"), e.timing())
+    ra, pa, resa, _ = outs["graphed"]
+    for tag in ("graphed4e", "graphed2", "single", "sync"):
+        rb, pb, resb, _ = outs[tag]
+        assert np.array_equal(ra["iters"], rb["iters"]) and np.array_equal(ra["err_bits"], rb["err_bits"]), (tag, ra["iters"], rb["iters"])
+        assert ra["err_now"].tobytes() == rb["err_now"].tobytes() and ra["ratio"].tobytes() == rb["ratio"].tobytes(), tag
+        assert biteq(pa, pb), tag
+        assert biteq(resa[:, 1:-1, 1:-1], resb[:, 1:-1, 1:-1]), tag
+    for m in (0, 5, 11):
+        want = H.diagnose_case(A[m], B[m], Cc[m], bc[m], **cfg)["BAROTROPIC"]
+        assert int(ra["iters"][m]) == want["iters"] and int(ra["err_bits"][m]) == want["err"]
+        assert biteq(pa[m], want["psi"]) and ra["err_now"][m].tobytes() == want["r1"].tobytes()
+    if max_iter == 20000:
+        stops = sorted(set(int(v) // 100 for v in ra["iters"] if v < max_iter))
+        assert len(set(c % 24 for c in stops)) >= 6, stops       # stops land on many slots of the ring
+
+
 def test_pipelined_other_check_steps():
     """check_step that is not a multiple of the blocked launch length, tiny converge_time."""
     nr, nz = 80, 56

@@ -89,7 +89,7 @@ def test_sweep_fullsize_kinds_match_the_reference_program():
         got[(op, rhs)] = (ens.download("PSI", first, 2), ens.download("ETA", first, 2))
     try:
         rec = sw.step(mi, on_stage=keep)
-        frac = {k: (t["redo_tiles_total"] + t["inline_redo_tiles"]) / t["tiles"] for k, t in sw.stage_timing.items()}
+        frac = {k: (t["redo_tiles"] + t["inline_redo_tiles"]) / t["tiles"] for k, t in sw.stage_timing.items()}
     finally:
         sw.close()
     for t, kinds in ((1, (0, 1, 2)), (0, (2,))):

@@ -70,7 +70,7 @@ def test_rim_driven_zero_rhs_matches_oracle(sync, op, n):
     assert int(rec["iters"]) == it and int(rec["err_bits"]) == eb and rec["err_now"].tobytes() == r1.tobytes()
     assert np.count_nonzero(psi[:, : nr - n - 2]) == 0       # the untouched part really is there
     # only the tiles at the front (values below the optimistic body's range) may take the exact body
-    assert (tm["redo_tiles_total"] + tm["inline_redo_tiles"]) <= 0.5 * tm["tiles"], tm
+    assert (tm["redo_tiles"] + tm["inline_redo_tiles"]) <= 0.5 * tm["tiles"], tm
 
 
 @pytest.mark.parametrize("op", [0, 1])
@@ -89,7 +89,7 @@ def test_all_zero_problem(op, fsign):
         assert biteq(gres[1:-1, 1:-1], res[1:-1, 1:-1]), opts
         assert rec["err_now"].tobytes() == r1.tobytes()
         if not opts:
-            assert tm["redo_tiles_total"] + tm["inline_redo_tiles"] == 0, tm
+            assert tm["redo_tiles"] + tm["inline_redo_tiles"] == 0, tm
 
 
 def test_partly_zero_with_negative_zero_and_patch():

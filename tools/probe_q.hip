@@ -48,13 +48,13 @@ int main(int argc, char** argv)
     for (int k = 0; k < 24; ++k) {
         if (k == 4) CK(hipEventRecord(e0, 0));
         hipLaunchKernelGGL((k_sweep_q<NW, R, false, true, true, false>), grid, dim3(NW * 64), 0, 0, g, (k & 1) ? psi1 : psi0, (k & 1) ? psi0 : psi1,
-                           base, f, (float*)nullptr, (float*)nullptr, (const MemberState*)nullptr, 1.0f, T, 0, redo, (unsigned long long*)nullptr, ntx, nty, 16);
+                           base, f, (float*)nullptr, (float*)nullptr, (const MemberState*)nullptr, 1.0f, T, 0, redo, (unsigned long long*)nullptr, ntx, nty);
     }
     CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
     float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
     const double plain_us = ms * 1e3 / 20.0;
     hipLaunchKernelGGL((k_sweep_q<NW, R, false, true, true, true>), grid, dim3(NW * 64), 0, 0, g, psi0, psi1, base, f, (float*)nullptr, (float*)nullptr,
-                       (const MemberState*)nullptr, 1.0f, T, 0, redo, stamps, ntx, nty, 16);
+                       (const MemberState*)nullptr, 1.0f, T, 0, redo, stamps, ntx, nty);
     CK(hipDeviceSynchronize());
     std::vector<unsigned long long> st(nwg * 32);
     CK(hipMemcpy(st.data(), stamps, nwg * 32 * 8, hipMemcpyDeviceToHost));

@@ -9,7 +9,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -59,7 +61,14 @@ int require_device()
     return XEE_OK;
 }
 
-bool g_setup_done = false;
+std::once_flag g_setup_once;
+int g_setup_status = 0;
+
+// what tests count instead of timing (xee_debug_counters): creations of device ensembles, device allocations made by the
+// Tier-1 entry points for host-layout staging, thread-exit releases of Tier-1 caches
+std::atomic<long long> g_n_ensembles{0}, g_n_tier1_stage_allocs{0}, g_n_thread_exit_releases{0};
+std::atomic<bool> g_process_exiting{false};
+struct ExitFlag { ~ExitFlag() { g_process_exiting.store(true); } } g_exit_flag;   // (statics die after the main thread's thread_locals)
 
 }  // namespace
 
@@ -67,13 +76,19 @@ namespace {
 // process-wide defaults of the run-time options: every ensemble created afterwards (the Tier-1 entry points
 // create theirs internally) starts from them
 struct Defaults { SweepOpts sweep{}; int sync_checks = 0; int exact_sum_serial = 0; } g_defaults;
+std::mutex g_defaults_mutex;                 // (any thread may set them while another creates an ensemble)
+Defaults read_defaults()
+{
+    std::lock_guard<std::mutex> lk(g_defaults_mutex);
+    return g_defaults;
+}
 
 // one table for both setters: key -> the int it controls and its admitted range
 int set_option_in(SweepOpts& o, int& sync_checks, int& exact_serial, const char* key, int value)
 {
     struct Ent { const char* key; int* p; int lo, hi; };
     const Ent tab[] = {{"tb_T", &o.T, 1, tb_max_T()}, {"kernel", &o.kernel, 0, 3}, {"q_exact_only", &o.q_exact_only, 0, 1},
-                       {"elision", &o.elision, 0, 1}, {"tile", &o.tile, 0, 9999}, {"sync_checks", &sync_checks, 0, 1},
+                       {"elision", &o.elision, 0, 1}, {"tile", &o.tile, 0, 9999}, {"graph_blocks", &o.graph_blocks, 0, 8}, {"graph_events", &o.graph_events, 0, 1}, {"sync_checks", &sync_checks, 0, 1},
                        {"exact_sum_serial", &exact_serial, 0, 1}};
     if (!key) return fail(XEE_ERR_INVALID_ARGUMENT, "null option key");
     for (const Ent& t : tab)
@@ -131,13 +146,23 @@ struct xee_ensemble {
     hipEvent_t evB[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};     // sweep block begin/end, by slot
     float* res2 = nullptr;       // residual planes of slots 1 and 2 (slot 0 is `res`); res3 only at depth 2
     float* res3 = nullptr;
-    float* snap = nullptr;       // 3 x members planes: the iterate right after each check iteration, by slot
+    float* snap = nullptr;       // (depth + 1) x members planes: the iterate right after each check iteration, by slot
+    int snap_planes = 0;
     MemberState* st_host2 = nullptr;   // pinned, 3 x members: the member states after a check, by slot (written by the device)
     void* ex_ws2 = nullptr;      // second check stream's norm workspace, sums and slow counters (depth 2 only)
     float* sums2 = nullptr;
     int* ex_slow2 = nullptr;
-    int* redo = nullptr;               // tile list of k_sweep_q's residual-writing launches (xee_sweepq.hip)
+    int* redo = nullptr;               // two diagnostic counters of k_sweep_q: tiles redone by the exact body (xee_sweepq.hip)
     std::map<int, float*> stash;       // device-resident copies of fields (xee_ensemble_field_save): key = field * 64 + slot
+    // solve_graphed (small batches): a ring of GS slots (residual plane, snapshot, event pair, pinned host copy of the states)
+    // and GV views of the member states
+    float* gres = nullptr;
+    float* gsnap = nullptr;
+    MemberState* gst_host = nullptr;   // pinned
+    MemberState* gst_view = nullptr;
+    hipEvent_t gevE[24] = {}, gevF[24] = {};
+    int g_slots = 0;                   // slots the ring was allocated for
+    float* aos_stage = nullptr;        // Tier 1: device staging of the reference's AoS coe(9,nx,ny), kept with the ensemble
     int win_first = 0, win_count = 0;  // member window of the forcing_* / field_save / field_restore calls (0 = all members)
     MemberState* st_view = nullptr;    // 4 x members: the sweeps' VIEWS of the member states in the pipelined driver.  The
                                        // state machine of check k writes view k % 4 (on a check stream); the sweeps read the
@@ -243,10 +268,6 @@ bool launch_blocked(xee_ensemble* e, const float* psi_in, float* psi_out, float*
     if (e->have_base && k != 1) {
         if (k == 2) launch_sweep_tb4(e->g, psi_in, psi_out, e->base, e->f, res, st, alpha, T, e->base_baro, e->opts, &e->last_sweep, e->stream);
         else {
-            if (!e->redo) {
-                if (hipMalloc(reinterpret_cast<void**>(&e->redo), sizeof(int) * sweep_q_redo_ints(e->g)) != hipSuccess) { e->redo = nullptr; return false; }   // (the launch check after the block reports it)
-                (void)hipMemsetAsync(e->redo, 0, sizeof(int) * sweep_q_redo_ints(e->g), e->stream);
-            }
             return launch_sweep_q(e->g, psi_in, psi_out, e->base, e->f, res, res ? snap : nullptr, st, alpha, T, e->base_baro, e->opts, e->redo, &e->last_sweep, e->stream);
         }
     }
@@ -347,22 +368,23 @@ int xee_ensemble_create(xee_ensemble_t** out, int nr, int nz, int n_members, int
     XCHK(require_device());
     if (device < 0) HIPCHK(hipGetDevice(&device));
     HIPCHK(hipSetDevice(device));
-    if (!g_setup_done) {
-        int s = sweep_kernel_setup();
-        if (s == 0) s = exact_kernel_setup();
-        if (s != 0) return fail(XEE_ERR_HIP, std::string("kernel setup: ") + hipGetErrorString((hipError_t)s));
-        g_setup_done = true;
-    }
+    std::call_once(g_setup_once, [] {
+        g_setup_status = sweep_kernel_setup();
+        if (g_setup_status == 0) g_setup_status = exact_kernel_setup();
+    });
+    if (g_setup_status != 0) return fail(XEE_ERR_HIP, std::string("kernel setup: ") + hipGetErrorString((hipError_t)g_setup_status));
     xee_ensemble* e = new xee_ensemble();
+    g_n_ensembles.fetch_add(1);
     e->device = device;
     e->g.nx = nr;
     e->g.ny = nz;
     e->g.pitch = ((nr + 63) / 64) * 64;
     e->g.members = n_members;
     e->g.plane = (size_t)e->g.pitch * nz;
-    e->opts = g_defaults.sweep;
-    e->sync_checks = g_defaults.sync_checks != 0;
-    e->exact_serial = g_defaults.exact_sum_serial != 0;
+    const Defaults dflt = read_defaults();
+    e->opts = dflt.sweep;
+    e->sync_checks = dflt.sync_checks != 0;
+    e->exact_serial = dflt.exact_sum_serial != 0;
     int st = XEE_OK;
     auto guard = [&](int s) { if (st == XEE_OK) st = s; };
     if (create_stream(&e->stream, true) != hipSuccess) { delete e; return fail(XEE_ERR_HIP, "hipStreamCreate failed"); }
@@ -375,6 +397,8 @@ int xee_ensemble_create(xee_ensemble_t** out, int nr, int nz, int n_members, int
     guard(alloc_planes(e, &e->psi[1]));
     guard(alloc_planes(e, &e->coe, 9));
     guard(alloc_planes(e, &e->res));
+    if (st == XEE_OK && hipMalloc(reinterpret_cast<void**>(&e->redo), 2 * sizeof(int)) != hipSuccess) guard(fail(XEE_ERR_ALLOC, "hipMalloc counters"));
+    if (st == XEE_OK && hipMemsetAsync(e->redo, 0, 2 * sizeof(int), e->stream) != hipSuccess) guard(fail(XEE_ERR_HIP, "memset counters"));
     if (st == XEE_OK && hipMalloc(reinterpret_cast<void**>(&e->st), sizeof(MemberState) * n_members) != hipSuccess) guard(fail(XEE_ERR_ALLOC, "hipMalloc state"));
     if (st == XEE_OK && hipMalloc(reinterpret_cast<void**>(&e->sums), sizeof(float) * n_members) != hipSuccess) guard(fail(XEE_ERR_ALLOC, "hipMalloc sums"));
     if (st == XEE_OK && hipHostMalloc(reinterpret_cast<void**>(&e->st_host), sizeof(MemberState) * n_members) != hipSuccess) guard(fail(XEE_ERR_ALLOC, "hipHostMalloc state"));
@@ -421,6 +445,13 @@ int xee_ensemble_destroy(xee_ensemble_t* e)
     if (e->st_view) hipFree(e->st_view);
     if (e->redo) hipFree(e->redo);
     for (auto& kv : e->stash) if (kv.second) hipFree(kv.second);
+    if (e->aos_stage) hipFree(e->aos_stage);
+    if (e->gres) hipFree(e->gres);
+    if (e->gsnap) hipFree(e->gsnap);
+    if (e->gst_host) hipHostFree(e->gst_host);
+    if (e->gst_view) hipFree(e->gst_view);
+    for (auto& ev : e->gevE) if (ev) hipEventDestroy(ev);
+    for (auto& ev : e->gevF) if (ev) hipEventDestroy(ev);
     if (e->st_host) hipHostFree(e->st_host);
     if (e->sums_host) hipHostFree(e->sums_host);
     for (auto& ev : e->ev) if (ev) hipEventDestroy(ev);
@@ -453,12 +484,21 @@ int xee_ensemble_set_case_ids(xee_ensemble_t* e, int first_case_id)
 
 int xee_set_default_option(const char* key, int value)
 {
+    std::lock_guard<std::mutex> lk(g_defaults_mutex);
     return set_option_in(g_defaults.sweep, g_defaults.sync_checks, g_defaults.exact_sum_serial, key, value);
 }
 
 int xee_reset_default_options(void)
 {
+    std::lock_guard<std::mutex> lk(g_defaults_mutex);
     g_defaults = Defaults{};
+    return XEE_OK;
+}
+
+int xee_debug_counters(int64_t* out /* 4 */)
+{
+    if (!out) return fail(XEE_ERR_INVALID_ARGUMENT, "null out");
+    out[0] = g_n_ensembles.load(); out[1] = g_n_tier1_stage_allocs.load(); out[2] = g_n_thread_exit_releases.load(); out[3] = 0;
     return XEE_OK;
 }
 
@@ -707,13 +747,16 @@ int solve_pipelined(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float 
     // batch -- beside the sweeps they took compute units from every launch of the next block (+12 % per sweep launch,
     // profiles/r02) -- and only the serial walk (one wave per member) and the state machine run in the shadow of the
     // sweeps.  A small batch leaves the machine half empty anyway: there the whole norm runs beside the sweeps.
-    const bool wide_on_sweep_stream = !e->exact_serial && (size_t)g.members * g.nx * g.ny >= ((size_t)4 << 20);
-    const int D = wide_on_sweep_stream ? 1 : 2;   // checks in flight behind the sweeps
+    // (the depth follows from the batch size alone; with option exact_sum_serial a large batch keeps depth 1 and its per-block
+    // events, only the norm -- then the serial reference-order walk -- runs whole on the check stream)
+    const bool large = (size_t)g.members * g.nx * g.ny >= ((size_t)4 << 20);
+    const bool wide_on_sweep_stream = large && !e->exact_serial;
+    const int D = large ? 1 : 2;                  // checks in flight behind the sweeps
     const int NS = D + 1;                         // slots (residual plane, snapshot, events, host copy of the states)
     constexpr int NV = 4;                         // views of the member states (see below)
-    const bool block_events = wide_on_sweep_stream;
-    if (!e->cstream[0]) {
-        HIPCHK(create_stream(&e->cstream[0], false));
+    const bool block_events = large;
+    if (!e->cstream[0]) HIPCHK(create_stream(&e->cstream[0], false));
+    if (!e->evE[0]) {
         for (auto& ev : e->evE) HIPCHK(hipEventCreate(&ev));
         for (auto& ev : e->evF) HIPCHK(hipEventCreate(&ev));
         for (auto& pr : e->evB) for (auto& ev : pr) HIPCHK(hipEventCreate(&ev));
@@ -737,7 +780,8 @@ int solve_pipelined(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float 
     const MemberState* view = e->st_view + (size_t)(NV - 1) * g.members;
     XCHK(alloc_planes(e, &e->res2));
     if (D == 2) XCHK(alloc_planes(e, &e->res3));
-    XCHK(alloc_planes(e, &e->snap, 3));
+    XCHK(alloc_planes(e, &e->snap, NS));
+    e->snap_planes = NS;
     hipStream_t cst[2] = {e->cstream[0], e->cstream[D - 1]};
     void* wsb[2] = {e->ex_ws, D == 2 ? e->ex_ws2 : e->ex_ws};
     float* sumb[2] = {e->sums, D == 2 ? e->sums2 : e->sums};
@@ -753,7 +797,7 @@ int solve_pipelined(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float 
     std::vector<int> stop_slot(g.members, -1);    // snapshot slot holding a stopped member's result
     std::vector<char> active(g.members, 1);
     e->timing = xee_timing_t{};
-    if (e->redo) HIPCHK(hipMemsetAsync(e->redo + sweep_q_redo_ints(g) - 2, 0, 2 * sizeof(int), s));   // the solve's diagnostic counters
+    HIPCHK(hipMemsetAsync(e->redo, 0, 2 * sizeof(int), s));   // the solve's diagnostic counters
     HIPCHK(hipEventRecord(e->ev[0], s));
     int cnt = 0, k = 0;                           // k = number of checks enqueued
     int digested = 0;                             // ... and of checks whose outcome the host has looked at
@@ -790,12 +834,7 @@ int solve_pipelined(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float 
         ~GraphCache() { for (auto& kv : m) { if (kv.second.exec) hipGraphExecDestroy(kv.second.exec); if (kv.second.graph) hipGraphDestroy(kv.second.graph); } }
     } graphs;
     // (not on the legacy default stream, which cannot be captured; any capture failure falls back to plain launches)
-    bool use_graphs = !wide_on_sweep_stream && tb_T > 1 && cs > tb_T && max_iter / cs >= 64 && s != nullptr;
-    if (use_graphs && !e->redo && e->have_base && e->opts.kernel != 1 && e->opts.kernel != 2) {
-        // (launch_blocked allocates the tile list on first use: not inside a capture)
-        HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->redo), sizeof(int) * sweep_q_redo_ints(g)));
-        HIPCHK(hipMemsetAsync(e->redo, 0, sizeof(int) * sweep_q_redo_ints(g), s));
-    }
+    bool use_graphs = !large && tb_T > 1 && cs > tb_T && max_iter / cs >= 64 && s != nullptr;
     // the launches from iteration `from` up to `target` (a check iteration gets the residual plane and the snapshot)
     auto enqueue_sweeps = [&](int from, int target, bool to_check, int sl, int* cur_io, bool* snapped, int* launches, long long* tiles) {
         int c2 = from;
@@ -923,11 +962,11 @@ int solve_pipelined(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float 
         HIPCHK(hipMemcpyAsync(e->psi[cur] + (size_t)m * g.plane, snapbuf[stop_slot[m]] + (size_t)m * g.plane,
                               sizeof(float) * g.plane, hipMemcpyDeviceToDevice, s));
     }
-    if (e->redo) {
-        int n[3] = {0, 0, 0};                     // last launch's redo list, all lists of the solve, in-workgroup fallbacks
-        HIPCHK(hipMemcpyAsync(n, e->redo + sweep_q_redo_ints(g) - 3, sizeof(n), hipMemcpyDeviceToHost, s));
+    {
+        int n[2] = {0, 0};                        // tiles redone by the exact body: residual-writing launches, plain launches
+        HIPCHK(hipMemcpyAsync(n, e->redo, sizeof(n), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
-        e->timing.redo_tiles = n[0]; e->timing.redo_tiles_total = n[1]; e->timing.inline_redo_tiles = n[2];
+        e->timing.redo_tiles = n[0]; e->timing.inline_redo_tiles = n[1];
     }
     // XEE_F_RESIDUAL = the residual plane of each member's LAST check (include/xee.h): checks rotated through the
     // slots' planes; a stopped member's is the one of its stopping check, everyone else's the one of the last check enqueued
@@ -942,6 +981,232 @@ int solve_pipelined(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float 
         HIPCHK(hipMemcpyAsync(e->ex_slow, e->ex_slow2, sizeof(int) * g.members, hipMemcpyDeviceToDevice, s));
     HIPCHK(hipStreamSynchronize(s));
     e->cur = cur;
+    return XEE_OK;
+}
+
+// solve_elliptic for a SMALL batch (one 1024x512 case: 242 workgroups per launch, a launch every 9 us): the sweeps of
+// GB consecutive check blocks are ONE graph of 52 kernels, and the sweep stream carries nothing else -- no event record
+// between blocks (each is a barrier packet that drains the queue: 6 us), one after the graph, at the boundary between two
+// graph launches where the queue drains anyway (16 us, now paid once per GB blocks).  The GB checks of a graph start when
+// the graph has ended and run, as in solve_pipelined, beside the sweeps of the NEXT graph (two check streams, only the
+// state machines chained).  Slots: a check's residual plane, snapshot, event and host copy of the member states live in
+// slot k % GS; the graph of checks [k, k + GB) is launched once every check up to k + GB - 1 - GS has been digested by the
+// host -- with GS = 3 GB those belong to the graph before the previous one, so the host never waits in steady state.
+// Views: check j's state machine writes view j % GS; the sweeps of the graph of checks [k, k + GB) are shown the view of
+// check k - GB - 1 (digested by then; the checks in flight, k - GB .. k + GB - 1, write other views), so a graph depends on
+// k % GS and the ping-pong phase only: three graphs per solve.  A member that stops is iterated on for up to GS more
+// blocks before the sweeps see
+// it -- harmless, its result is the snapshot of its stopping check (whose slot is not overwritten: by the time the slot
+// comes round again the sweeps skip the member), but wasted work: the driver is used for long solves only.
+int solve_graphed(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float alpha, int tb_T, bool* ran)
+{
+    // blocks per graph: the option's value, but no more than four when the ring (3 GB slots of two planes) would exceed 128 MB
+    const int GB = (e->opts.graph_blocks > 4 && (size_t)e->g.members * e->g.plane * sizeof(float) > ((size_t)2 << 20) + 65536) ? 4 : e->opts.graph_blocks;
+    const int GS = 3 * GB, GV = GS + 1;                       // view GS = the initial states (never written)
+    const bool block_events = e->opts.graph_events != 0;     // (experiment: an external event record per block inside the graph)
+    const Grid& g = e->g;
+    hipStream_t s = e->stream;
+    *ran = false;
+    if (!e->cstream[0]) HIPCHK(create_stream(&e->cstream[0], false));
+    if (!e->cstream[1]) {
+        HIPCHK(create_stream(&e->cstream[1], false));
+        HIPCHK(hipMalloc(&e->ex_ws2, exact_ws_bytes(g)));
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->sums2), sizeof(float) * g.members));
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->ex_slow2), sizeof(int) * g.members));
+    }
+    if (e->gres && e->g_slots < GS) {
+        HIPCHK(hipStreamSynchronize(s));
+        hipFree(e->gres); hipFree(e->gsnap); hipHostFree(e->gst_host); hipFree(e->gst_view);
+        e->gres = e->gsnap = nullptr; e->gst_host = e->gst_view = nullptr;
+    }
+    if (!e->gres) {
+        e->g_slots = GS;
+        XCHK(alloc_planes(e, &e->gres, GS));
+        XCHK(alloc_planes(e, &e->gsnap, GS));
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->gst_host), sizeof(MemberState) * GS * g.members));
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->gst_view), sizeof(MemberState) * GV * g.members));
+        for (auto& ev : e->gevE) if (!ev) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        for (auto& ev : e->gevF) if (!ev) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    const size_t mp = (size_t)g.members * g.plane;
+    for (int v = 0; v < GV; ++v)
+        HIPCHK(hipMemcpyAsync(e->gst_view + (size_t)v * g.members, e->st, sizeof(MemberState) * g.members, hipMemcpyDeviceToDevice, s));
+    // every snapshot slot starts as a full copy of the first guess (the rim never changes; the sweeps store interior points)
+    for (int sl = 0; sl < GS; sl += 2) launch_copy2(g, e->psi[e->cur], e->gsnap + sl * mp, e->gsnap + (sl + 1) * mp, s);
+    hipStream_t cst[2] = {e->cstream[0], e->cstream[1]};
+    void* wsb[2] = {e->ex_ws, e->ex_ws2};
+    float* sumb[2] = {e->sums, e->sums2};
+    int* slowb[2] = {e->ex_slow, e->ex_slow2};
+
+    int cur = e->cur;
+    std::vector<int> stop_slot(g.members, -1);
+    std::vector<char> active(g.members, 1);
+    e->timing = xee_timing_t{};
+    HIPCHK(hipMemsetAsync(e->redo, 0, 2 * sizeof(int), s));
+    HIPCHK(hipEventRecord(e->ev[0], s));
+    int cnt = 0, k = 0, digested = 0;
+    bool all_done = false, converging = false;    // converging: an active member met the criteria at the newest digested check
+    const int n_checks = max_iter / cs;
+
+    auto digest_upto = [&](int j) -> int {
+        for (; digested <= j; ++digested) {
+            const int sl = digested % GS;
+            HIPCHK(hipEventSynchronize(e->gevF[sl]));
+            const MemberState* sh = e->gst_host + (size_t)sl * g.members;
+            all_done = true;
+            converging = false;
+            for (int m = 0; m < g.members; ++m) {
+                if (active[m] && !sh[m].active) { active[m] = 0; stop_slot[m] = sl; }
+                if (sh[m].active) { all_done = false; converging = converging || sh[m].converge_cnt > 0; }
+            }
+            memcpy(e->st_host, sh, sizeof(MemberState) * g.members);
+        }
+        return XEE_OK;
+    };
+    // the launches of ONE check block on stream s, from iteration `from` to the check iteration `from + cs`
+    auto enqueue_block = [&](int from, int sl, const MemberState* view, int* cur_io, int* launches, long long* tiles) {
+        int c2 = from;
+        const int target = from + cs;
+        bool snapped = false;
+        while (c2 < target) {
+            const int rem = (target - c2) % tb_T;
+            const int n = rem ? rem : tb_T;             // the short launch first: the residual-writing one is full-length
+            c2 += n;
+            const bool check = c2 == target;
+            e->last_sweep.tiles = 0;
+            if (n == 1)
+                launch_sweep(g, e->psi[*cur_io], e->psi[*cur_io ^ 1], e->coe, e->f, check ? e->gres + sl * mp : nullptr, view, alpha, s);
+            else if (launch_blocked(e, e->psi[*cur_io], e->psi[*cur_io ^ 1], check ? e->gres + sl * mp : nullptr, alpha, n, view,
+                                    check ? e->gsnap + sl * mp : nullptr))
+                snapped = true;
+            *cur_io ^= 1;
+            *launches += 1;
+            *tiles += e->last_sweep.tiles;
+        }
+        if (!snapped) launch_copy_active(g, e->psi[*cur_io], e->gsnap + sl * mp, view, s);
+    };
+    struct BlockGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int launches = 0; long long tiles = 0; int flips = 0; };
+    struct GraphCache {
+        std::map<int, BlockGraph> m;
+        ~GraphCache() { for (auto& kv : m) { if (kv.second.exec) hipGraphExecDestroy(kv.second.exec); if (kv.second.graph) hipGraphDestroy(kv.second.graph); } }
+    } graphs;
+    bool use_graphs = true;
+
+    while (k < n_checks && !all_done) {
+        // a whole graph -- or single blocks: at the tail, and while a member is counting down to its stop (whatever is
+        // enqueued behind a stop is wasted work: up to GS blocks of it with whole graphs, three with single blocks)
+        const int gb = (n_checks - k >= GB && use_graphs && !converging) ? GB : 1;
+        // the slots about to be written are free (one more than needed: at most GS - 1 checks in flight, so that none of them
+        // writes the view shown to the sweeps), and the view's check has been digested.  A graph is shown the states after
+        // check k - GB - 1 -- a function of k alone, so that only GS / GB distinct graphs exist per ping-pong phase -- single
+        // blocks the newest digested one.
+        XCHK(digest_upto(k + gb - GS));
+        if (gb == GB) XCHK(digest_upto(k - GB - 1));
+        if (all_done) break;
+        const int vi = gb == GB ? (k >= GB + 1 ? (k - GB - 1) % GS : GS) : (digested >= 1 ? (digested - 1) % GS : GS);
+        const MemberState* view = e->gst_view + (size_t)vi * g.members;
+        int launches = 0;
+        long long tiles = 0;
+        if (gb == GB) {
+            const int key = cur | ((k % GS) << 1) | ((vi == GS ? 1 : 0) << 7);     // ping-pong phase x first slot (x the initial view)
+            BlockGraph& bg = graphs.m[key];
+            if (!bg.exec) {
+                int c2 = cur;
+                if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess) {
+                    bool ok = true;
+                    for (int i = 0; i < GB; ++i) {
+                        enqueue_block(cnt + i * cs, (k + i) % GS, view, &c2, &bg.launches, &bg.tiles);
+                        if (block_events && i + 1 < GB) ok = ok && hipEventRecordWithFlags(e->gevE[(k + i) % GS], s, hipEventRecordExternal) == hipSuccess;
+                    }
+                    if (hipStreamEndCapture(s, &bg.graph) != hipSuccess || !ok || hipGraphInstantiate(&bg.exec, bg.graph, nullptr, nullptr, 0) != hipSuccess)
+                        bg.exec = nullptr;
+                    bg.flips = c2 ^ cur;
+                }
+                if (!bg.exec) { (void)hipGetLastError(); use_graphs = false; graphs.m.erase(key); continue; }   // single blocks from here on
+            }
+            HIPCHK(hipGraphLaunch(bg.exec, s));
+            launches = bg.launches; tiles = bg.tiles; cur ^= bg.flips;
+        } else {
+            enqueue_block(cnt, k % GS, view, &cur, &launches, &tiles);
+        }
+        const int ev_last = (k + gb - 1) % GS;
+        HIPCHK(hipEventRecord(e->gevE[ev_last], s));                     // the residual planes of checks k .. k + gb - 1 are written
+        e->timing.sweep_launches += launches;
+        e->timing.tiles += tiles;
+        e->timing.iterations += (int64_t)gb * cs;
+        for (int i = 0; i < gb; ++i, ++k) {
+            const int sl = k % GS, ci = k % 2;
+            hipStream_t c = cst[ci];
+            cnt += cs;
+            HIPCHK(hipStreamWaitEvent(c, e->gevE[block_events ? sl : ev_last], 0));
+            if (e->exact_serial) launch_seqsum(g, e->gres + sl * mp, 1, g.nx - 1, 1, g.ny - 1, true, sumb[ci], e->st, c);
+            else launch_exact_sumsq(g, e->gres + sl * mp, wsb[ci], sumb[ci], slowb[ci], e->st, c);
+            if (k >= 1) HIPCHK(hipStreamWaitEvent(c, e->gevF[(k - 1) % GS], 0));     // the state machine is sequential in the checks
+            cp.cnt = cnt;
+            cp.is_last = cnt == max_iter ? 1 : 0;
+            launch_conv_update(g, sumb[ci], e->st, cp, c, e->gst_view + (size_t)sl * g.members, e->gst_host + (size_t)sl * g.members);
+            HIPCHK(hipEventRecord(e->gevF[sl], c));
+            e->timing.check_launches += 1;
+        }
+        XCHK(check_launch("sweep/check (graphed)"));
+        XCHK(digest_upto(k - 1 - (gb == GB ? GB : 2)));                    // the host stays one graph (or two single blocks) behind the sweeps
+    }
+    // iterations past the last check (max_iter is not a multiple of check_step): every check settled first, then :242-248
+    XCHK(digest_upto(k - 1));
+    for (int i = 0; i < 2; ++i) HIPCHK(hipStreamSynchronize(cst[i]));
+    const bool stopped_early = all_done;
+    bool tail_ran = false;
+    if (!stopped_early && cnt < max_iter) {
+        // (the members still active take the remaining iterations from psi[cur]; they see the final states)
+        int c2 = cnt;
+        while (c2 < max_iter) {
+            const int n = (max_iter - c2) < tb_T ? (max_iter - c2) : tb_T;
+            e->last_sweep.tiles = 0;
+            if (n == 1) launch_sweep(g, e->psi[cur], e->psi[cur ^ 1], e->coe, e->f, nullptr, e->st, alpha, s);
+            else launch_blocked(e, e->psi[cur], e->psi[cur ^ 1], nullptr, alpha, n, e->st, nullptr);
+            cur ^= 1; c2 += n;
+            e->timing.sweep_launches += 1; e->timing.tiles += e->last_sweep.tiles;
+        }
+        e->timing.iterations += max_iter - cnt;
+        launch_finalize(g, e->st, max_iter, s);
+        HIPCHK(hipMemcpyAsync(e->st_host, e->st, sizeof(MemberState) * g.members, hipMemcpyDeviceToHost, s));
+        tail_ran = true;
+    }
+    HIPCHK(hipEventRecord(e->ev[2], s));
+    HIPCHK(hipEventRecord(e->ev[1], s));
+    HIPCHK(hipStreamSynchronize(s));
+    XCHK(check_launch("solve (graphed)"));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e->ev[0], e->ev[1]));
+    e->timing.solve_ms = ms;
+    e->timing.sweep_ms = ms;                       // (the sweep stream carries nothing but sweeps)
+
+    // :259-264  results into one plane.  A member that stopped at a check has been iterated further meanwhile: its result is
+    // the snapshot of its stopping check -- unless that was the very last thing enqueued and it ran to max_iter
+    const bool tail_clean = !tail_ran && k >= 1 && cnt == max_iter;
+    for (int m = 0; m < g.members; ++m) {
+        if (stop_slot[m] < 0) continue;                                       // ended by finalize: psi[cur] is it
+        if (tail_clean && stop_slot[m] == ((k - 1) % GS) && e->st_host[m].iters == max_iter) continue;
+        HIPCHK(hipMemcpyAsync(e->psi[cur] + (size_t)m * g.plane, e->gsnap + stop_slot[m] * mp + (size_t)m * g.plane,
+                              sizeof(float) * g.plane, hipMemcpyDeviceToDevice, s));
+    }
+    {
+        int n[2] = {0, 0};
+        HIPCHK(hipMemcpyAsync(n, e->redo, sizeof(n), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        e->timing.redo_tiles = n[0]; e->timing.inline_redo_tiles = n[1];
+    }
+    // XEE_F_RESIDUAL = the residual plane of each member's LAST check
+    for (int m = 0; m < g.members && k >= 1; ++m) {
+        const int slot = stop_slot[m] >= 0 ? stop_slot[m] : ((k - 1) % GS);
+        HIPCHK(hipMemcpyAsync(e->res + (size_t)m * g.plane, e->gres + slot * mp + (size_t)m * g.plane, sizeof(float) * g.plane,
+                              hipMemcpyDeviceToDevice, s));
+    }
+    if (k >= 1 && ((k - 1) % 2) == 1 && !e->exact_serial)
+        HIPCHK(hipMemcpyAsync(e->ex_slow, e->ex_slow2, sizeof(int) * g.members, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    e->cur = cur;
+    *ran = true;
     return XEE_OK;
 }
 
@@ -981,7 +1246,12 @@ int xee_ensemble_solve(xee_ensemble_t* e, int max_iter, int check_step, int conv
     // default: residual checks pipelined behind the sweeps; option "sync_checks" (or the per-check
     // trace, whose lines must appear in order) selects the simple synchronous driver below
     if (!e->sync_checks && cp.debug == 0) {
-        XCHK(solve_pipelined(e, max_iter, cs, cp, alpha, tb_T));
+        // a small batch with a long solve ahead: several check blocks per graph (solve_graphed); else one block at a time
+        const bool small = (size_t)g.members * g.nx * g.ny < ((size_t)4 << 20);
+        bool ran = false;
+        if (small && e->opts.graph_blocks && tb_T > 1 && cs > tb_T && max_iter / cs >= 64 && s != nullptr)
+            XCHK(solve_graphed(e, max_iter, cs, cp, alpha, tb_T, &ran));
+        if (!ran) XCHK(solve_pipelined(e, max_iter, cs, cp, alpha, tb_T));
         for (int m = 0; m < g.members; ++m) {
             xee_case_record_t& r = e->rec[m];
             r.iters = e->st_host[m].iters;
@@ -993,7 +1263,7 @@ int xee_ensemble_solve(xee_ensemble_t* e, int max_iter, int check_step, int conv
     }
 
     e->timing = xee_timing_t{};
-    if (e->redo) HIPCHK(hipMemsetAsync(e->redo + sweep_q_redo_ints(g) - 2, 0, 2 * sizeof(int), s));
+    HIPCHK(hipMemsetAsync(e->redo, 0, 2 * sizeof(int), s));
     HIPCHK(hipEventRecord(e->ev[0], s));
     bool block_open = false;
     int cnt = 0;
@@ -1053,10 +1323,10 @@ int xee_ensemble_solve(xee_ensemble_t* e, int max_iter, int check_step, int conv
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, e->ev[0], e->ev[1]));
     e->timing.solve_ms = ms;
-    if (e->redo) {
-        int n[3] = {0, 0, 0};
-        HIPCHK(hipMemcpy(n, e->redo + sweep_q_redo_ints(g) - 3, sizeof(n), hipMemcpyDeviceToHost));
-        e->timing.redo_tiles = n[0]; e->timing.redo_tiles_total = n[1]; e->timing.inline_redo_tiles = n[2];
+    {
+        int n[2] = {0, 0};
+        HIPCHK(hipMemcpy(n, e->redo, sizeof(n), hipMemcpyDeviceToHost));
+        e->timing.redo_tiles = n[0]; e->timing.inline_redo_tiles = n[1];
     }
 
     // :259-264  every member's result into one plane.  A stopped member's planes are never touched
@@ -1306,6 +1576,22 @@ namespace {
 // it explicitly (it holds device memory: about forty planes of the last grid).
 struct Tier1Cache { xee_ensemble_t* e = nullptr; int nx = 0, ny = 0; };
 thread_local Tier1Cache g_t1;
+void tier1_release_all();
+// A thread that ends (a pool worker, an OpenMP team member) releases what its Tier-1 calls kept on the device: the
+// reference's procedures are stateless, so such a caller has no reason to call xee_tier1_release itself.  The main
+// thread's thread_locals die before any static object does, i.e. while the HIP runtime is still up; a thread that ends
+// later than that (during process exit) leaks instead.
+struct Tier1ThreadGuard {
+    bool armed = false;
+    ~Tier1ThreadGuard()
+    {
+        if (armed && !g_process_exiting.load()) { tier1_release_all(); g_n_thread_exit_releases.fetch_add(1); }
+    }
+};
+thread_local Tier1ThreadGuard g_t1_guard;
+// caches above this many bytes of planes are not kept between calls: a solve on such a grid takes seconds, the 15 ms of
+// a fresh ensemble do not matter, and ~50 planes of a 4096x2048 grid are 1.7 GB
+constexpr size_t kTier1KeepBytes = (size_t)1 << 30;
 
 void tier1_drop()
 {
@@ -1323,14 +1609,15 @@ int tier1_reset(xee_ensemble* e)
         if (p) HIPCHK(hipMemsetAsync(p, 0, pb, s));
     if (e->coe) HIPCHK(hipMemsetAsync(e->coe, 0, 9 * pb, s));
     if (e->base) HIPCHK(hipMemsetAsync(e->base, 0, 4 * pb, s));
-    if (e->snap) HIPCHK(hipMemsetAsync(e->snap, 0, 3 * pb, s));
+    if (e->snap) HIPCHK(hipMemsetAsync(e->snap, 0, e->snap_planes * pb, s));
+    if (e->gres) { HIPCHK(hipMemsetAsync(e->gres, 0, e->g_slots * pb, s)); HIPCHK(hipMemsetAsync(e->gsnap, 0, e->g_slots * pb, s)); }
     const size_t nv = (size_t)(e->g.nx > e->g.ny ? e->g.nx : e->g.ny) + 64;
     for (float* v : {e->ra, e->za, e->rcuva, e->rho, e->exner})
         if (v) HIPCHK(hipMemsetAsync(v, 0, nv * sizeof(float), s));
-    if (e->redo) HIPCHK(hipMemsetAsync(e->redo, 0, sizeof(int) * sweep_q_redo_ints(e->g), s));
-    e->opts = g_defaults.sweep;
-    e->sync_checks = g_defaults.sync_checks != 0;
-    e->exact_serial = g_defaults.exact_sum_serial != 0;
+    const Defaults dflt = read_defaults();
+    e->opts = dflt.sweep;
+    e->sync_checks = dflt.sync_checks != 0;
+    e->exact_serial = dflt.exact_sum_serial != 0;
     e->have_profiles = false;
     e->have_base = false;
     e->base_baro = false;
@@ -1354,6 +1641,7 @@ struct Tier1 {
     int acquire(int nx, int ny)
     {
         failures0 = g_failures;
+        g_t1_guard.armed = true;
         int dev = 0;
         if (g_t1.e && (g_t1.nx != nx || g_t1.ny != ny || hipGetDevice(&dev) != hipSuccess || dev != g_t1.e->device)) tier1_drop();
         if (g_t1.e) {
@@ -1366,7 +1654,12 @@ struct Tier1 {
         e = g_t1.e;
         return XEE_OK;
     }
-    ~Tier1() { if (e && g_failures != failures0) tier1_drop(); }   // (whatever went wrong, the next call starts afresh)
+    ~Tier1()
+    {
+        if (!e) return;
+        // whatever went wrong, the next call starts afresh; and a large grid's planes are not held between calls
+        if (g_failures != failures0 || e->g.plane * sizeof(float) * 50 > kTier1KeepBytes) tier1_drop();
+    }
 };
 }  // namespace
 
@@ -1400,6 +1693,7 @@ int cache_store(xee_ensemble* e, const float* b_host, float dx, float dy)
 {
     CoeCache& cc = g_cc;
     cc.valid = false;
+    if (sizeof(float) * 12 * e->g.plane > kTier1KeepBytes) return XEE_OK;   // too large to keep: the solve takes the nine-plane kernel
     if (cc.device != e->device || cc.plane != e->g.plane) {
         if (cc.abc) hipFree(cc.abc);
         if (cc.coe) hipFree(cc.coe);
@@ -1466,6 +1760,20 @@ int xee_last_sweep_info(char* name, int name_len, int* T, int* tile_w, int* tile
     return XEE_OK;
 }
 
+namespace {
+// the device staging buffer for the reference's AoS coe(9,nx,ny), allocated once per kept ensemble
+int aos_stage(xee_ensemble* e, float** out)
+{
+    if (!e->aos_stage) {
+        const size_t bytes = sizeof(float) * 9 * (size_t)e->g.nx * e->g.ny;
+        if (hipMalloc(reinterpret_cast<void**>(&e->aos_stage), bytes) != hipSuccess) { e->aos_stage = nullptr; return fail(XEE_ERR_ALLOC, "hipMalloc coe staging"); }
+        g_n_tier1_stage_allocs.fetch_add(1);
+    }
+    *out = e->aos_stage;
+    return XEE_OK;
+}
+}  // namespace
+
 int xee_cal_coe(const float* a, const float* b, const float* c, float* coe, float dx, float dy, int nx, int ny, int* err)
 {
     if (!a || !b || !c || !coe || !err) return fail(XEE_ERR_INVALID_ARGUMENT, "null argument");
@@ -1479,13 +1787,12 @@ int xee_cal_coe(const float* a, const float* b, const float* c, float* coe, floa
     launch_cal_coe(e->g, e->sA, e->sB, e->sC, e->coe, dx, dy, e->stream);
     float* aos = nullptr;
     const size_t bytes = sizeof(float) * 9 * (size_t)nx * ny;
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&aos), bytes));
+    XCHK(aos_stage(e, &aos));
     // only interior entries are written (the reference leaves the rim untouched): start from the caller's bytes
     hipError_t he = hipMemcpyAsync(aos, coe, bytes, hipMemcpyHostToDevice, e->stream);
     if (he == hipSuccess) { launch_coe_soa_to_aos(e->g, e->coe, aos, e->stream); he = hipMemcpyAsync(coe, aos, bytes, hipMemcpyDeviceToHost, e->stream); }
     if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
     if (he == hipSuccess) he = hipGetLastError();
-    hipFree(aos);
     if (he != hipSuccess) return fail(XEE_ERR_HIP, std::string("xee_cal_coe: ") + hipGetErrorString(he));
     XCHK(cache_store(e, b, dx, dy));
     *err = 0;                                                   // :58
@@ -1496,11 +1803,10 @@ static int upload_coe_aos(xee_ensemble_t* e, const float* coe)
 {
     float* aos = nullptr;
     const size_t bytes = sizeof(float) * 9 * (size_t)e->g.nx * e->g.ny;
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&aos), bytes));
+    XCHK(aos_stage(e, &aos));
     hipError_t he = hipMemcpyAsync(aos, coe, bytes, hipMemcpyHostToDevice, e->stream);
     if (he == hipSuccess) { launch_coe_aos_to_soa(e->g, aos, e->coe, e->stream); he = hipStreamSynchronize(e->stream); }
     if (he == hipSuccess) he = hipGetLastError();
-    hipFree(aos);
     if (he != hipSuccess) return fail(XEE_ERR_HIP, std::string("coe upload: ") + hipGetErrorString(he));
     return detect_uniform_planes(e);
 }

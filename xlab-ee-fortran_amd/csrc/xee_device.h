@@ -90,6 +90,10 @@ struct SweepOpts {
     int q_exact_only = 0;  // "q_exact_only": k_sweep_q runs its exact body on every tile
     int elision = 1;       // "elision": k_sweep_tb skips coefficient planes that are uniform over the batch
     int tile = 0;          // "tile": NW*100 + R (waves x rows per lane), 0 = the kernel's default
+    int graph_blocks = 8;  // "graph_blocks": check blocks per graph for small batches (solve_graphed), 1..8; 0: one block at a time
+    int graph_events = 0;  // "graph_events": 1 = an external event record per block inside the graph (its check starts at once);
+                           //                 0 = one record behind the graph (the checks of a graph start when it has ended): default,
+                           //                 121.8 against 126.7 ms per 100,000 iterations of one 1024x512 case (profiles/r03)
 };
 // what the last blocked launch was (xee_ensemble_sweep_info)
 struct SweepDesc {
@@ -122,9 +126,8 @@ void launch_sweep_tb4(const Grid& g, const float* psi_in, float* psi_out, const 
 bool launch_sweep_q(const Grid& g, const float* psi_in, float* psi_out, const float* base, const float* f,
                     float* res, float* snap /* residual-writing launches: a second copy of the new iterate's valid points, or nullptr */,
                     const MemberState* st, float alpha, int T, bool barotropic, const SweepOpts& o,
-                    int* redo /* device, sweep_q_redo_ints(g) ints: tiles a residual-writing launch leaves to the exact body */,
+                    int* diag /* device, 2 ints or nullptr: tiles redone by the exact body in residual-writing / plain launches */,
                     SweepDesc* desc, hipStream_t s);
-size_t sweep_q_redo_ints(const Grid& g);
 void launch_quotient_check(unsigned long long seed, int blocks, int per_thread, int d_exp_lo, int d_exp_hi,
                            unsigned long long* mismatches /* device, 2 words */, float* first_bad /* device, 2 */,
                            hipStream_t s);

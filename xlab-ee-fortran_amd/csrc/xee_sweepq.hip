@@ -561,25 +561,23 @@ __device__ __forceinline__ void exact_tile(const Grid& g, const TileGeom& tg, fl
         __syncthreads();
         const float below = (w > 0) ? edge[par][0][w - 1][lane] : 0.0f;
         const float above = (w < NW - 1) ? edge[par][1][w + 1][lane] : 0.0f;
-        float lft[R + 2], rgt[R + 2];
-        lft[0] = qshr1(below); rgt[0] = qshl1(below);
-#pragma unroll
-        for (int r = 0; r < R; ++r) { lft[r + 1] = qshr1(src[r]); rgt[r + 1] = qshl1(src[r]); }
-        lft[R + 1] = qshr1(above); rgt[R + 1] = qshl1(above);
+        // (the lane shifts are taken where they are used -- six per row instead of two: this body runs for the few tiles the
+        // optimistic one rejects, and the 2 (R + 2) registers of shifted copies were what made the residual-writing
+        // kernel, which inlines both bodies, spill)
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const float om = (r > 0) ? src[r - 1] : below;
             const float oc = src[r];
             const float on = (r + 1 < R) ? src[r + 1] : above;
-            float Rv = c[0][r] * lft[r + 2];              // elliptic_tools.f90:77-85, left to right
+            float Rv = c[0][r] * qshr1(on);               // elliptic_tools.f90:77-85, left to right
             Rv = Rv + c[1][r] * on;
-            Rv = Rv + c[2][r] * rgt[r + 2];
-            Rv = Rv + c[3][r] * lft[r + 1];
+            Rv = Rv + c[2][r] * qshl1(on);
+            Rv = Rv + c[3][r] * qshr1(oc);
             Rv = Rv + c[4][r] * oc;
-            Rv = Rv + c[5][r] * rgt[r + 1];
-            Rv = Rv + c[6][r] * lft[r];
+            Rv = Rv + c[5][r] * qshl1(oc);
+            Rv = Rv + c[6][r] * qshr1(om);
             Rv = Rv + c[7][r] * om;
-            Rv = Rv + c[8][r] * rgt[r];
+            Rv = Rv + c[8][r] * qshl1(om);
             Rv = Rv - ff[r];                              // :190
             const float upd = oc + alpha * Rv / (-c[4][r]);   // :238
             const int gy = gy0 + r;
@@ -648,16 +646,17 @@ constexpr int q_waves_per_simd()
     const int regs = R * (BARO ? 9 : 13);
     return regs <= 78 ? 4 : (regs <= 208 ? 2 : 1);       // star: R <= 8 | R <= 16(+) ; nine weights: R <= 6 | R <= 16
 }
-// A tile the optimistic body rejects is redone by the exact body: in this same workgroup for the plain variant; the
-// residual-writing variant (one launch per check) only APPENDS the tile to `redo` ([0] = count, then tile numbers) and
-// k_sweep_q_redo, launched right behind it, walks that list -- with both bodies inlined the residual-writing kernel
-// spilled to scratch, and a kernel that uses scratch is throttled at dispatch (158 us for 4 iterations against 105 us
-// for 6 of the plain variant, profiles/r02).
+// A tile the optimistic body rejects is redone by the exact body in this same workgroup, from its unchanged inputs.
+// (Round 2 kept a device-side list and a second kernel for the residual-writing variant: with both bodies inlined it
+// spilled to scratch, and a kernel that uses scratch is throttled at dispatch.  The exact body now takes its lane shifts
+// where it uses them instead of holding 2 (R + 2) shifted copies, both bodies fit 128 VGPRs, and the list, its kernel and
+// one launch per check -- 4.4 us of a single case's 136-us block -- are gone.)
+// diag[0] / diag[1] count the tiles redone by residual-writing / plain launches (xee_timing_t).
 template <int NW, int R, bool WRITE_R, bool BARO, bool ALPHA1, bool STAMP = false>
 __global__ __launch_bounds__(NW * 64, (q_waves_per_simd<NW, R, BARO>())) void k_sweep_q(Grid g, const float* __restrict__ psi_in,
         float* __restrict__ psi_out, const float* __restrict__ base, const float* __restrict__ f,
         float* __restrict__ res, float* __restrict__ snap, const MemberState* __restrict__ st, float alpha, int T, int exact_only,
-        int* __restrict__ redo, unsigned long long* __restrict__ stamps, int ntx, int nty, int cnt_slot)
+        int* __restrict__ diag, unsigned long long* __restrict__ stamps, int ntx, int nty)
 {
     __shared__ float edge[2][2][NW][64];
     __shared__ int vote[NW];
@@ -688,40 +687,9 @@ __global__ __launch_bounds__(NW * 64, (q_waves_per_simd<NW, R, BARO>())) void k_
             return;
         }
     }
-    if constexpr (WRITE_R) {
-        if (threadIdx.x == 0) {
-            const int slot = atomicAdd(redo, 1);
-            redo[1 + slot] = tile;                         // = (member * nty + row) * ntx + column
-        }
-    } else {
-        if (threadIdx.x == 0 && redo && !exact_only) atomicAdd(redo + cnt_slot + 3, 1);   // diagnostic: in-workgroup fallbacks
-        exact_tile<NW, R, WRITE_R, BARO>(g, tg, edge, psi_in, psi_out, base, f, res, snap, alpha, T, member);
-    }
+    if (threadIdx.x == 0 && diag && !exact_only) atomicAdd(diag + (WRITE_R ? 0 : 1), 1);
+    exact_tile<NW, R, WRITE_R, BARO>(g, tg, edge, psi_in, psi_out, base, f, res, snap, alpha, T, member);
     stamp<STAMP>(tg, 6);
-}
-
-// the tiles a residual-writing launch left to the exact body (usually none: the grid then finds count == 0 and ends)
-template <int NW, int R, bool BARO>
-__global__ __launch_bounds__(NW * 64) void k_sweep_q_redo(Grid g, const float* __restrict__ psi_in, float* __restrict__ psi_out,
-        const float* __restrict__ base, const float* __restrict__ f, float* __restrict__ res, float* __restrict__ snap,
-        const MemberState* __restrict__ st, float alpha, int T, int* __restrict__ redo, int ntx, int nty, int done_slot)
-{
-    __shared__ float edge[2][2][NW][64];
-    const int count = redo[0];
-    for (int i = blockIdx.x; i < count; i += gridDim.x) {
-        const int id = redo[1 + i];
-        const int bx = id % ntx, by = (id / ntx) % nty, m = id / (ntx * nty);
-        const TileGeom tg = make_geom<NW, R>(g, T, bx, by, m);
-        exact_tile<NW, R, true, BARO>(g, tg, edge, psi_in, psi_out, base, f, res, snap, alpha, T, st ? st + m : nullptr);
-        __syncthreads();                                  // the edge rows are reused by the next tile
-    }
-    // the list is consumed: the last workgroup to get here empties it for the next residual-writing launch
-    // (redo[done_slot] counts arrivals, redo[done_slot + 1] keeps the count for xee_timing_t.redo_tiles, [done_slot + 2]
-    // their sum since the solve began; every workgroup has read redo[0] before it arrives)
-    if (threadIdx.x == 0) {
-        __threadfence();
-        if (atomicAdd(redo + done_slot, 1) == (int)gridDim.x - 1) { redo[done_slot + 1] = count; redo[done_slot + 2] += count; redo[0] = 0; redo[done_slot] = 0; __threadfence(); }
-    }
 }
 
 // validation kernel for the quotient identity: n pairs per thread drawn from a counter-based generator
@@ -782,35 +750,23 @@ __global__ __launch_bounds__(256) void k_quotient_check(unsigned long long seed,
 
 template <int NW, int R, bool BARO>
 static void launch_q_cfg(const Grid& g, const float* psi_in, float* psi_out, const float* base, const float* f,
-                         float* res, float* snap, const MemberState* st, float alpha, int T, int exact_only, int* redo, SweepDesc* desc, hipStream_t s)
+                         float* res, float* snap, const MemberState* st, float alpha, int T, int exact_only, int* diag, SweepDesc* desc, hipStream_t s)
 {
     constexpr int H = NW * R;
     const int ntx = (g.nx - 1 + (64 - 2 * T) - 1) / (64 - 2 * T), nty = (g.ny - 1 + (H - 2 * T) - 1) / (H - 2 * T);
     const long long ntile = (long long)ntx * nty * g.members;
     const dim3 grid((unsigned)(8 * ((ntile + 7) / 8)));    // one-dimensional, a multiple of eight: see the kernel's tile order
     const bool a1 = alpha == 1.0f;     // the protocol's damping: 1.0f * x is x, the multiply is not issued
-#define Q_LAUNCH(WR, A1) hipLaunchKernelGGL((k_sweep_q<NW, R, WR, BARO, A1>), grid, dim3(NW * 64), 0, s, g, psi_in, psi_out, base, f, res, snap, st, alpha, T, exact_only, redo, (unsigned long long*)nullptr, ntx, nty, (int)sweep_q_redo_ints(g) - 4)
+#define Q_LAUNCH(WR, A1) hipLaunchKernelGGL((k_sweep_q<NW, R, WR, BARO, A1>), grid, dim3(NW * 64), 0, s, g, psi_in, psi_out, base, f, res, snap, st, alpha, T, exact_only, diag, (unsigned long long*)nullptr, ntx, nty)
     if (desc) desc->tiles = ntile;
-    if (res) {                         // (redo[0] is zero here: zeroed at allocation, and by every k_sweep_q_redo when it ends)
-        if (a1) Q_LAUNCH(true, true); else Q_LAUNCH(true, false);
-        hipLaunchKernelGGL((k_sweep_q_redo<NW, R, BARO>), dim3(exact_only ? 1024 : 64), dim3(NW * 64), 0, s, g, psi_in, psi_out, base, f, res, snap, st,
-                           alpha, T, redo, ntx, nty, (int)sweep_q_redo_ints(g) - 4);
-    }
+    if (res) { if (a1) Q_LAUNCH(true, true); else Q_LAUNCH(true, false); }
     else { if (a1) Q_LAUNCH(false, true); else Q_LAUNCH(false, false); }
 #undef Q_LAUNCH
 }
 
-size_t sweep_q_redo_ints(const Grid& g)
-{
-    // the count, one slot per tile of the densest tiling launch_sweep_q admits (tile steps >= 16 columns, >= 8 rows), the
-    // redo kernel's arrival counter, the last launch's count, the count summed over the solve and the number of tiles the
-    // plain launches redid inside their workgroup (diagnostics: the last four ints); the caller zeroes the buffer once
-    return (size_t)g.members * ((g.nx + 15) / 16) * ((g.ny + 7) / 8) + 5;
-}
-
 bool launch_sweep_q(const Grid& g, const float* psi_in, float* psi_out, const float* base, const float* f,
                     float* res, float* snap, const MemberState* st, float alpha, int T, bool barotropic, const SweepOpts& o,
-                    int* redo, SweepDesc* desc, hipStream_t s)
+                    int* diag, SweepDesc* desc, hipStream_t s)
 {
     // the buffer descriptors address one member's plane with 32-bit byte offsets: a plane of 2 GiB or more (a 23,000 x 23,000
     // grid) goes to the kernel with 64-bit addressing
@@ -831,8 +787,8 @@ bool launch_sweep_q(const Grid& g, const float* psi_in, float* psi_out, const fl
     if ((cfg / 100) * (cfg % 100) - 2 * T < 8) cfg = 808;           // the tile must keep a useful core
     if (desc) { desc->name = barotropic ? "k_sweep_q<star>" : "k_sweep_q<nine>"; desc->T = T; desc->tile_w = 64; desc->tile_h = (cfg / 100) * (cfg % 100); }
 #define Q_CASE(NW, R) case NW * 100 + R: \
-        if (barotropic) launch_q_cfg<NW, R, true>(g, psi_in, psi_out, base, f, res, snap, st, alpha, T, exact_only, redo, desc, s); \
-        else launch_q_cfg<NW, R, false>(g, psi_in, psi_out, base, f, res, snap, st, alpha, T, exact_only, redo, desc, s); \
+        if (barotropic) launch_q_cfg<NW, R, true>(g, psi_in, psi_out, base, f, res, snap, st, alpha, T, exact_only, diag, desc, s); \
+        else launch_q_cfg<NW, R, false>(g, psi_in, psi_out, base, f, res, snap, st, alpha, T, exact_only, diag, desc, s); \
         break;
     switch (cfg) {
         Q_CASE(8, 8)

@@ -13,7 +13,7 @@ import numpy as np
 
 _HERE = Path(__file__).resolve().parent
 
-__all__ = ["Ensemble", "Comm", "comm_unique_id", "comm_available", "comm_library", "comm_set_timeout", "COMM_ID_BYTES", "XeeError", "lib", "lib_path", "device_count", "set_default_option", "reset_default_options", "last_sweep_info", "tier1_release",
+__all__ = ["debug_counters", "Ensemble", "Comm", "comm_unique_id", "comm_available", "comm_library", "comm_set_timeout", "COMM_ID_BYTES", "XeeError", "lib", "lib_path", "device_count", "set_default_option", "reset_default_options", "last_sweep_info", "tier1_release",
            "profiles", "cal_coe", "do_elliptic", "solve_elliptic", "solver_coefficients", "residual_norm", "cal_eta", "cal_uw",
            "integrate_weight_B", "cal_sum_Qeta", "cal_wtheta", "rhs_thermal", "rhs_from_B", "rhs_momentum", "fd_stencil",
            "exchange_conversion", "legacy_averages", "JJ_B", "add_fields", "diagnose_case", "CaseRecord", "RECORD_DTYPE", "Timing", "FIELDS", "FD_STENCILS",
@@ -54,7 +54,7 @@ assert RECORD_DTYPE.itemsize == 128 and C.sizeof(CaseRecord) == 128
 class Timing(C.Structure):
     _fields_ = [("solve_ms", C.c_double), ("sweep_ms", C.c_double), ("sweep_launches", C.c_int64),
                 ("iterations", C.c_int64), ("check_launches", C.c_int64), ("redo_tiles", C.c_int64),
-                ("redo_tiles_total", C.c_int64), ("inline_redo_tiles", C.c_int64), ("tiles", C.c_int64)]
+                ("inline_redo_tiles", C.c_int64), ("tiles", C.c_int64)]
 
 
 _lib = None
@@ -406,6 +406,13 @@ def comm_unique_id():
     buf = C.create_string_buffer(COMM_ID_BYTES)
     _chk(lib().xee_comm_unique_id(buf))
     return buf.raw
+
+
+def debug_counters():
+    """-> dict(ensembles, tier1_stage_allocs, thread_exit_releases): process-wide counts (xee_debug_counters)"""
+    out = (C.c_int64 * 4)()
+    _chk(lib().xee_debug_counters(out))
+    return {"ensembles": out[0], "tier1_stage_allocs": out[1], "thread_exit_releases": out[2]}
 
 
 def comm_available():
