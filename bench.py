@@ -203,10 +203,12 @@ def main():
     ap.add_argument("--max-iter", type=int, default=100000)
     ap.add_argument("--cpu-sample-iters", type=int, default=500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="ensemble", choices=["ensemble", "single", "highres", "baroclinic", "sweep"],
+    ap.add_argument("--workload", default="ensemble", choices=["ensemble", "single", "highres", "baroclinic", "sweep", "sor"],
                     help="ensemble (default: the bench line) | single (configs[1]: one case) | highres (configs[3]: one "
                          "4096x2048 case, 2,000 iterations) | baroclinic (the ensemble with the full-B operator) | sweep "
-                         "(configs[4]: per timestep {L(B=0), L(B)} x {-B, thermal, zero RHS with a rim boundary})")
+                         "(configs[4]: per timestep {L(B=0), L(B)} x {-B, thermal, zero RHS with a rim boundary}) | sor (OPT-IN, "
+                         "non-parity: the red/black SOR smoother run to the residual the reference's 100,000 Jacobi iterations reach)")
+    ap.add_argument("--omega", type=float, default=1.992, help="--workload sor: over-relaxation factor (optimal for 1024x512: 1.9923)")
     ap.add_argument("--sweep-split", action="store_true", help="--workload sweep: six (operator, kind) stages one after the "
                     "other instead of one fused batch per operator -- slower, but per_stage then separates the kinds")
     args = ap.parse_args()
@@ -250,6 +252,8 @@ def main():
     nr, nz, M = args.nr, args.nz, args.members
     if args.workload == "sweep":
         return bench_sweep(args, xee, torch, dist, rank, local_rank, world, rehearsal, coll_dev)
+    if args.workload == "sor":
+        return bench_sor(args, xee, torch, rank, local_rank, world)
     operator = "BAROCLINIC" if args.workload == "baroclinic" else "BAROTROPIC"
     prof = xee.profiles(nr, nz, 0, 0, (0.0, 1.0, 0.0, 1.0))
     ens = xee.Ensemble(nr, nz, M, device=local_rank)
@@ -386,6 +390,94 @@ def main():
         comm.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def bench_sor(args, xee, torch, rank, local_rank, world):
+    """OPT-IN, NON-PARITY workload (the north star's "red/black SOR"): how long the over-relaxed
+    smoother takes to get as close to the fixed point of the iteration as the reference's damped Jacobi is after its
+    100,000 iterations -- and to 1e-3 of it -- on the bench's own 32 x 1024x512 ensemble.  RMS residuals cannot be the
+    yardstick: in fp32 they bottom out at ~6e-8 x |c psi| (1e-5 .. 1e-4 here), above what the unconverged Jacobi iterate of
+    some members shows.  So: psi* = the SOR iterate at its floor (4,000 iterations); error = max over members of
+    ||psi - psi*||_2 / ||psi*||_2; the Jacobi case is run once, untimed here (bench.py's default workload times it)."""
+    if world != 1:
+        raise SystemExit("--workload sor is a one-GPU measurement")
+    nr, nz, M = args.nr, args.nz, args.members
+    ens = xee.Ensemble(nr, nz, M, device=local_rank)
+    ens.set_profiles(xee.profiles(nr, nz, 0, 0, (0.0, 1.0, 0.0, 1.0)))
+    for m in range(M):
+        A, B, Cc, bc, Q = member_fields(nr, nz, m)
+        for name, arr in (("A", A), ("B", B), ("C", Cc), ("BC_INIT", bc), ("Q", Q)):
+            ens.upload(name, arr, first=m)
+    ens.forcing_from_B(); ens.assemble(xee.BAROTROPIC)
+
+    def err_to(ref):
+        psi = ens.download("PSI").astype(np.float64)
+        d = np.sqrt(((psi - ref) ** 2).sum(axis=(1, 2))) / np.sqrt((ref ** 2).sum(axis=(1, 2)))
+        return float(d.max())
+
+    rs = ens.solve_sor(4000, 1e-30, -1.0, args.omega, check_step=1000, converge_time=1)
+    star = ens.download("PSI").astype(np.float64)
+    floor = [float(rs["err_now"].min()), float(rs["err_now"].max())]
+    t0 = time.perf_counter()
+    rj = ens.solve(args.max_iter, 1e-8, -1.0, 1.0)
+    torch.cuda.synchronize()
+    jacobi_s = time.perf_counter() - t0
+    err_j = err_to(star)
+    # how many SOR iterations until every member is as close as the Jacobi iterate, and until 1e-3 (scanned in steps of 10)
+    need, n, first = {}, 0, True
+    while n < 4000 and len(need) < 2:
+        ens.solve_sor(10, 1e-30, -1.0, args.omega, check_step=10, converge_time=1, flags=0 if first else xee.SOLVE_KEEP_PSI)
+        first = False
+        n += 10
+        e_now = err_to(star)
+        if "as_close_as_jacobi_100000" not in need and e_now <= err_j:
+            need["as_close_as_jacobi_100000"] = (n, e_now)
+        if "to_1e-3_of_the_fixed_point" not in need and e_now <= 1e-3:
+            need["to_1e-3_of_the_fixed_point"] = (n, e_now)
+
+    def run(n_it):
+        ens.forcing_from_B(); ens.assemble(xee.BAROTROPIC)
+        rec = ens.solve_sor(n_it, 1e-30, -1.0, args.omega, check_step=n_it, converge_time=1)
+        ens.cal_eta()
+        ens.ee_scalars()
+        return rec
+
+    out_t = {}
+    for tag, (n_it, e_now) in need.items():
+        for _ in range(args.warmup):
+            run(n_it)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            rec = run(n_it)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        tm = ens.timing()
+        out_t[tag] = {"iterations": n_it, "error": e_now, "ms_per_step": dt * 1e3, "cases_per_s": M / dt,
+                      "residual_range": [float(rec["err_now"].min()), float(rec["err_now"].max())],
+                      "us_per_iteration": tm["solve_ms"] * 1e3 / n_it}
+    a = out_t.get("as_close_as_jacobi_100000")
+    interior = (nr - 2) * (nz - 2)
+    b = out_t.get("to_1e-3_of_the_fixed_point") or a
+    # one red/black iteration: each half sweep reads psi, AP, CQ, f and writes psi; the two colours share their lines, so every
+    # line of the four planes is fetched and the psi line written twice per iteration: 2 x 20 B per point
+    gbps = 2 * 20.0 * interior * M / (b["us_per_iteration"] * 1e-6) / 1e9 if b else 0.0
+    out = {"metric": "diagnosed cases/s (1024x512 r-z grid, OPT-IN red/black SOR until as close to the fixed point as the reference's 100,000 "
+                     "Jacobi iterations get; not bit-parity)",
+           "value": a["cases_per_s"] if a else 0.0, "unit": "cases/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": a["ms_per_step"] if a else None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+           "data": "synthetic",
+           "config": {"workload": f"[sor] {M} x {nr}x{nz}, BAROTROPIC, omega {args.omega}; a step = forcing, K1+K2, N red/black iterations, one "
+                                  "residual check, cal_eta, EE scalars", "nr": nr, "nz": nz, "members_per_gpu": M, "omega": args.omega,
+                      "kernel": ens.sweep_info()["name"]},
+           "jacobi_reference": {"ms_per_step": jacobi_s * 1e3, "cases_per_s": M / jacobi_s, "iterations": args.max_iter,
+                                "error_to_the_fixed_point": err_j, "residual_range": [float(rj["err_now"].min()), float(rj["err_now"].max())]},
+           "sor_residual_floor_range": floor, "targets": out_t,
+           "speedup_over_jacobi_to_the_same_error": jacobi_s / (a["ms_per_step"] * 1e-3) if a else None,
+           "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBS, "traffic": None,
+                        "note": "k_sor_base<red/black>: 40 B per point and iteration (two half sweeps x 20 B) over the device time of the solve"}}
+    print(json.dumps(out), flush=True)
+    ens.close()
 
 
 def make_record_comm(xee, dist, rank, local_rank, world, rehearsal):

@@ -41,6 +41,13 @@ def test_sor_reaches_the_jacobi_fixed_point_much_faster(variant, inputs):
     with setup_ensemble(A, B, Cc, bc, variant, domain) as ens:
         rs = ens.solve_sor(6000, max(10.0 * floor, 1e-12), 5e-2, 1.85, check_step=20, converge_time=2)
         psi_s = ens.download("PSI")[0]
+        # from the operator's generating planes; B = 0 couples no diagonal neighbours: red/black, two half sweeps per iteration
+        assert ens.timing()["sweep_launches"] == (2 if variant == 0 else 4) * int(rs["iters"][0])
+    with setup_ensemble(A, B, Cc, bc, variant, domain) as ens:
+        ens.set_option("kernel", 1)                        # the nine-plane four-colour form: same answer to solver tolerance
+        r9 = ens.solve_sor(6000, max(10.0 * floor, 1e-12), 5e-2, 1.85, check_step=20, converge_time=2)
+        assert int(r9["err_bits"][0]) == 0 and ens.timing()["sweep_launches"] == 4 * int(r9["iters"][0])
+        assert np.abs(ens.download("PSI")[0] - psi_s).max() <= 2e-3 * np.abs(psi_s).max()
     assert int(rs["err_bits"][0]) == 0, ("SOR should converge by its criteria", rs["iters"], rs["err_now"], floor)
     assert int(rs["iters"][0]) * 10 <= 60000, rs["iters"]
     scale = np.abs(psi_j).max()

@@ -1372,15 +1372,19 @@ int xee_ensemble_solve_sor(xee_ensemble_t* e, int max_iter, int check_step, int 
     if (!(flags & XEE_SOLVE_KEEP_PSI)) { launch_copy2(g, e->bc, e->psi[0], e->psi[1], s); e->cur = 0; }
     launch_state_init(g, e->st, s);
     e->timing = xee_timing_t{};
+    e->last_sweep = SweepDesc{(e->have_base && e->opts.kernel != 1) ? (e->base_baro ? "k_sor_base<red/black>" : "k_sor_base<4 colours>") : "k_sor_color", 1, g.nx, g.ny};
     HIPCHK(hipEventRecord(e->ev[0], s));
     bool all_done = (max_iter == 0);
     for (int cnt = 1; cnt <= max_iter && !all_done; ++cnt) {
-        launch_sor_iteration(g, e->psi[e->cur], e->coe, e->f, e->st, omega, s);
-        e->timing.sweep_launches += 4;
+        const bool from_base = e->have_base && e->opts.kernel != 1;
+        if (from_base) launch_sor_iteration_base(g, e->psi[e->cur], e->base, e->f, e->st, omega, e->base_baro, s);
+        else launch_sor_iteration(g, e->psi[e->cur], e->coe, e->f, e->st, omega, s);
+        e->timing.sweep_launches += (from_base && e->base_baro) ? 2 : 4;
         e->timing.iterations += 1;
         const bool check = (cnt % cs) == 0, last = cnt == max_iter;
         if (check) {
-            launch_residual(g, e->psi[e->cur], e->coe, e->f, e->res, e->st, s);
+            if (from_base) launch_residual_base(g, e->psi[e->cur], e->base, e->f, e->res, e->st, e->base_baro, s);
+            else launch_residual(g, e->psi[e->cur], e->coe, e->f, e->res, e->st, s);
             launch_exact_sumsq(g, e->res, e->ex_ws, e->sums, e->ex_slow, e->st, s);
             cp.cnt = cnt;
             cp.is_last = last ? 1 : 0;

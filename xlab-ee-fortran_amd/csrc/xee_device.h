@@ -137,6 +137,11 @@ void launch_sor_iteration(const Grid& g, float* psi, const float* coe, const flo
                           float omega, hipStream_t s);
 void launch_residual(const Grid& g, const float* psi, const float* coe, const float* f, float* res,
                      const MemberState* st, hipStream_t s);
+// ... the same from the operator's generating planes; BAROTROPIC: red/black (two half sweeps per iteration)
+void launch_sor_iteration_base(const Grid& g, float* psi, const float* base, const float* f, const MemberState* st,
+                               float omega, bool barotropic, hipStream_t s);
+void launch_residual_base(const Grid& g, const float* psi, const float* base, const float* f, float* res,
+                          const MemberState* st, bool barotropic, hipStream_t s);
 // sequential fp32 sum, reference loop order (i outer, j inner), of T or T*T over a sub-rectangle
 void launch_seqsum(const Grid& g, const float* T, int i0, int i1, int j0, int j1, bool square,
                    float* out_sums, const MemberState* st, hipStream_t s);

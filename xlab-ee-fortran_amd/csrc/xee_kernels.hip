@@ -444,6 +444,99 @@ __global__ __launch_bounds__(256) void k_residual(Grid g, const float* __restric
     res[o] = r - f[o];
 }
 
+// The same smoother fed by the operator's four generating planes AP, CQ, BX, BY (k_base_planes: 16-24 B per point instead
+// of the nine coefficient planes' 36).  BAROTROPIC (b = 0): the stencil is the five-point star, which couples no diagonal
+// neighbours, so RED/BLACK ordering decouples it -- two in-place half sweeps per iteration instead of four colour passes.
+// weights as elliptic_tools.f90:46-54; NCOL = 2: colour = (i + j) & 1, NCOL = 4: (i & 1, j & 1).
+template <bool BARO>
+__device__ __forceinline__ float sor_residual_base(const Grid& g, const float* __restrict__ psi, const float* __restrict__ base,
+                                                   const float* __restrict__ f, size_t o, float* c5_out)
+{
+    const size_t ks = (size_t)g.members * g.plane;
+    const int p = g.pitch;
+    const float Ap = base[o], Am = base[o - 1], Cp = base[o + ks], Cm = base[o + ks - p];
+    float r;
+    float c5;
+    if constexpr (BARO) {
+        c5 = -(Am + Ap + Cm + Cp);
+        r = Cp * psi[o + p];
+        r = r + Am * psi[o - 1];
+        r = r + c5 * psi[o];
+        r = r + Ap * psi[o + 1];
+        r = r + Cm * psi[o - p];
+    } else {
+        const float BXp = base[o + 2 * ks], BXm = base[o + 2 * ks - 1], BYp = base[o + 3 * ks], BYm = base[o + 3 * ks - p];
+        c5 = -(Am + Ap + Cm + Cp);
+        r = (-(BXm + BYp)) * psi[o + p - 1];
+        r = r + (Cp + (BXp - BXm)) * psi[o + p];
+        r = r + (BXp + BYp) * psi[o + p + 1];
+        r = r + (Am - (BYp - BYm)) * psi[o - 1];
+        r = r + c5 * psi[o];
+        r = r + (Ap + (BYp - BYm)) * psi[o + 1];
+        r = r + (BXm + BYm) * psi[o - p - 1];
+        r = r + (Cm - (BXp - BXm)) * psi[o - p];
+        r = r + (-(BXp + BYm)) * psi[o - p + 1];
+    }
+    *c5_out = c5;
+    return r - f[o];
+}
+
+template <bool BARO>
+__global__ __launch_bounds__(256) void k_sor_base(Grid g, float* __restrict__ psi, const float* __restrict__ base,
+        const float* __restrict__ f, const MemberState* __restrict__ st, float omega, int colour)
+{
+    const int m = blockIdx.z;
+    if (st && !st[m].active) return;
+    int i, j;
+    if constexpr (BARO) {                                 // red/black: every row, every other column
+        j = blockIdx.y * 4 + threadIdx.y;
+        i = 2 * (blockIdx.x * 64 + threadIdx.x) + ((j + colour) & 1);
+    } else {
+        i = 2 * (blockIdx.x * 64 + threadIdx.x) + (colour & 1);
+        j = 2 * (blockIdx.y * 4 + threadIdx.y) + (colour >> 1);
+    }
+    if (i < 1 || i > g.nx - 2 || j < 1 || j > g.ny - 2) return;
+    const size_t o = (size_t)m * g.plane + (size_t)j * g.pitch + i;
+    float c5;
+    const float r = sor_residual_base<BARO>(g, psi, base, f, o, &c5);
+    psi[o] = psi[o] + omega * r / (-c5);
+}
+
+template <bool BARO>
+__global__ __launch_bounds__(256) void k_residual_base(Grid g, const float* __restrict__ psi, const float* __restrict__ base,
+        const float* __restrict__ f, float* __restrict__ res, const MemberState* __restrict__ st)
+{
+    const int m = blockIdx.z;
+    if (st && !st[m].active) return;
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int j = blockIdx.y * 4 + threadIdx.y;
+    if (i < 1 || i > g.nx - 2 || j < 1 || j > g.ny - 2) return;
+    const size_t o = (size_t)m * g.plane + (size_t)j * g.pitch + i;
+    float c5;
+    res[o] = sor_residual_base<BARO>(g, psi, base, f, o, &c5);
+}
+
+void launch_sor_iteration_base(const Grid& g, float* psi, const float* base, const float* f, const MemberState* st,
+                               float omega, bool barotropic, hipStream_t s)
+{
+    const dim3 blk(64, 4, 1);
+    if (barotropic) {
+        const dim3 grid(((g.nx + 1) / 2 + 63) / 64, (g.ny + 3) / 4, g.members);
+        for (int c = 0; c < 2; ++c) hipLaunchKernelGGL(k_sor_base<true>, grid, blk, 0, s, g, psi, base, f, st, omega, c);
+    } else {
+        const dim3 grid(((g.nx + 1) / 2 + 63) / 64, ((g.ny + 1) / 2 + 3) / 4, g.members);
+        for (int c = 0; c < 4; ++c) hipLaunchKernelGGL(k_sor_base<false>, grid, blk, 0, s, g, psi, base, f, st, omega, c);
+    }
+}
+
+void launch_residual_base(const Grid& g, const float* psi, const float* base, const float* f, float* res,
+                          const MemberState* st, bool barotropic, hipStream_t s)
+{
+    const dim3 grid((g.nx + 63) / 64, (g.ny + 3) / 4, g.members), blk(64, 4, 1);
+    if (barotropic) hipLaunchKernelGGL(k_residual_base<true>, grid, blk, 0, s, g, psi, base, f, res, st);
+    else hipLaunchKernelGGL(k_residual_base<false>, grid, blk, 0, s, g, psi, base, f, res, st);
+}
+
 void launch_sor_iteration(const Grid& g, float* psi, const float* coe, const float* f, const MemberState* st,
                           float omega, hipStream_t s)
 {
