@@ -290,12 +290,14 @@ def main():
     sweep_ms = 0.0
     iters = 0
     launches = 0
+    streams = 1
     for _ in range(args.steps):
         rec = step()
         t = ens.timing()
         sweep_ms += t["sweep_ms"]
         iters += t["iterations"]
         launches += t["sweep_launches"]
+        streams = max(1, t["sweep_streams"])
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -311,8 +313,11 @@ def main():
         kernel, tb_T = info["kernel"], info["T"]
         point_iters = float(interior) * M * iters                        # this rank, all timed steps
         tflops = FLOP_PER_POINT_ITER * point_iters / sweep_s / 1e12 if sweep_s > 0 else 0.0
-        avg_launch_s = sweep_s / max(launches, 1)
-        ent = traffic_entry(kernel, nr, nz, M, operator)
+        # (a large batch runs as two halves of its members side by side: `launches` counts both halves', each over M / 2
+        # members; one launch lasts sweep_s / (launches / streams), which is what a profiler reports per kernel)
+        avg_launch_s = sweep_s / max(launches / streams, 1)
+        members_per_launch = M / streams
+        ent = traffic_entry(kernel, nr, nz, members_per_launch, operator)
         # the committed counters are quoted only when they were taken on exactly this build of the kernel and driver
         here = current_build_hash()
         traffic_source = {"file": "profiles/traffic.json", "entry_found": ent is not None,
@@ -324,12 +329,13 @@ def main():
         traffic = ent["bytes_per_launch"] if ent else None
         b_alg = BYTES_RECOMPUTE[operator]
         hbm = {"algorithmic_bytes_per_point_iter": b_alg,
-               "compulsory_bytes_per_launch": b_alg * interior * M,       # one blocked pass touches every plane once
+               "compulsory_bytes_per_launch": b_alg * interior * members_per_launch,   # one blocked pass touches every plane once
+               # (all concurrent launches together: `streams` of them run side by side)
                "compulsory_GBps": b_alg * interior * M / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0,
                "effective_GBps": b_alg * point_iters / sweep_s / 1e9 if sweep_s > 0 else 0.0,
                "effective_GBps_48B_reference_formulation": BYTES_48 * point_iters / sweep_s / 1e9 if sweep_s > 0 else 0.0,
-               "real_GBps": traffic / avg_launch_s / 1e9 if traffic and avg_launch_s > 0 else None,
-               "real_frac_of_peak": traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS if traffic and avg_launch_s > 0 else None,
+               "real_GBps": traffic * streams / avg_launch_s / 1e9 if traffic and avg_launch_s > 0 else None,
+               "real_frac_of_peak": traffic * streams / avg_launch_s / 1e9 / HBM_PEAK_GBS if traffic and avg_launch_s > 0 else None,
                "peak_GBps": HBM_PEAK_GBS,
                "note": "temporal blocking: T iterations per pass over the planes, so the effective rates may exceed the HBM peak; "
                        "real_* is measured traffic (PMC) over the launch time"}
@@ -354,11 +360,12 @@ def main():
                          "peak_spec": VALU_SPEC_TFLOPS, "frac_of_spec": tflops / VALU_SPEC_TFLOPS,
                          "peak_unpacked": VALU_UNPACKED_TFLOPS, "frac_of_unpacked_peak": tflops / VALU_UNPACKED_TFLOPS,
                          # SQ_ACTIVE_INST_VALU counts quad-cycles a SIMD spent issuing VALU work (MI355X_MICROARCH.md, PMC units)
-                         "valu_busy_measured": (ent["SQ_ACTIVE_INST_VALU"] * 4.0 / (avg_launch_s * CLOCK_GHZ * 1e9 * N_SIMD)
+                         "valu_busy_measured": (ent["SQ_ACTIVE_INST_VALU"] * streams * 4.0 / (avg_launch_s * CLOCK_GHZ * 1e9 * N_SIMD)
                                                 if ent and ent.get("SQ_ACTIVE_INST_VALU") and avg_launch_s > 0 else None),
                          "flop_per_point_iter": FLOP_PER_POINT_ITER,
                          "kernel": f"{info['name']} (damped-Jacobi sweep, {tb_T} iteration(s) per launch, tile {info['tile']})",
-                         "avg_launch_us": avg_launch_s * 1e6, "launches": launches,
+                         "avg_launch_us": avg_launch_s * 1e6, "launches": launches, "concurrent_launches": streams,
+                         "members_per_launch": members_per_launch,
                          "point_iterations_per_launch": point_iters / max(launches, 1),
                          "valu_insts_per_launch": ent.get("SQ_INSTS_VALU") if ent else None,
                          "traffic_source": traffic_source,
@@ -563,7 +570,8 @@ def bench_sweep(args, xee, torch, dist, rank, local_rank, world, rehearsal, coll
         for (opn, rhsn), a in acc.items():
             sweep_s = a["sweep_ms"] * 1e-3
             kinds[f"{opn}/{rhsn}"] = {
-                "avg_launch_us": sweep_s / max(a["sweep_launches"], 1) * 1e6,
+                "avg_launch_us": sweep_s / max(a["sweep_launches"] / max(a["sweep_streams"] // args.steps, 1), 1) * 1e6,
+                "concurrent_launches": max(a["sweep_streams"] // args.steps, 1),
                 "redo_tile_fraction": (a["redo_tiles"] + a["inline_redo_tiles"]) / max(a["tiles"], 1),
                 "redo_tiles": a["redo_tiles"], "inline_redo_tiles": a["inline_redo_tiles"], "tiles": a["tiles"],
                 "solve_ms_per_stage": a["solve_ms"] / args.steps,
@@ -571,6 +579,7 @@ def bench_sweep(args, xee, torch, dist, rank, local_rank, world, rehearsal, coll
                 "TFLOPs": FLOP_PER_POINT_ITER * interior * nm * a["iterations"] / sweep_s / 1e12 if sweep_s > 0 else None}
         tot_sweep_s = sum(a["sweep_ms"] for a in acc.values()) * 1e-3
         tot_launch = sum(a["sweep_launches"] for a in acc.values())
+        streams_sw = max(max(a["sweep_streams"] // args.steps for a in acc.values()), 1)
         tot_pi = float(interior) * nm * sum(a["iterations"] for a in acc.values())
         tflops = FLOP_PER_POINT_ITER * tot_pi / tot_sweep_s / 1e12 if tot_sweep_s > 0 else 0.0
         out = {
@@ -588,7 +597,8 @@ def bench_sweep(args, xee, torch, dist, rank, local_rank, world, rehearsal, coll
             "all_cases_ran_to_max_iter": bool(np.all(rec["iters"] == args.max_iter)),
             "roofline": {"bound": "valu", "achieved": tflops, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": tflops / VALU_PEAK_TFLOPS, "traffic": None,
-                         "avg_launch_us": tot_sweep_s / max(tot_launch, 1) * 1e6, "launches": tot_launch,
+                         "avg_launch_us": tot_sweep_s / max(tot_launch / streams_sw, 1) * 1e6, "launches": tot_launch,
+                         "concurrent_launches": streams_sw,
                          "kernel": "k_sweep_q (both operator bodies; see per_stage)"},
             "per_stage": kinds,
         }

@@ -277,6 +277,10 @@ typedef struct {
     int64_t inline_redo_tiles; /* ... and in the plain launches; 0 on the common path */
     int64_t tiles;             /* tile executions of the blocked sweep in the last solve (launches x tiles per launch):
                                   (redo_tiles + inline_redo_tiles) / tiles = the fraction that took the exact body */
+    int64_t sweep_streams;     /* 1, or 2 when a large batch was solved as two halves of its member range side by side: then
+                                  sweep_launches counts both halves' launches (each over half the members) and sweep_ms is the
+                                  longer of the two halves' sweep times -- the average duration of one launch, as a profiler
+                                  sees it, is sweep_ms / (sweep_launches / sweep_streams) */
 } xee_timing_t;
 
 /* flags of xee_ensemble_solve */

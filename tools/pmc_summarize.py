@@ -96,11 +96,15 @@ def main():
         T, H = 8, (64 if op == "BAROTROPIC" else 48)
         planes = 4 if op == "BAROTROPIC" else 6
         ntx, nty = -(-(nr - 1) // (64 - 2 * T)), -(-(nz - 1) // (H - 2 * T))
-        lower = planes * nr * nz * 4.0 * M                                   # every plane byte once
-        upper = ntx * nty * M * (planes * 64 * H + (1 if planes == 4 else 2) * 64) * 4.0   # every tile its whole footprint
+        # members per LAUNCH: a large batch is solved as two halves side by side (xee_timing_t.sweep_streams), each launch
+        # then covers half the members -- read it off the grid (workgroups = tiles rounded up to a multiple of eight)
+        wgs = fmeta[kname]["grid"] // fmeta[kname]["wg"]
+        ML = max(1, min(M, round(wgs / (ntx * nty))))
+        lower = planes * nr * nz * 4.0 * ML                                  # every plane byte once
+        upper = ntx * nty * ML * (planes * 64 * H + (1 if planes == 4 else 2) * 64) * 4.0  # every tile its whole footprint
         read_bytes = max(min(2.0 * fetch * 1024.0, upper), lower)
         corr = fetch * 1024.0 / read_bytes
-        rec = {"workload": wl, "kernel": kname, "short": short(kname), "nr": nr, "nz": nz, "members": M, "operator": op,
+        rec = {"workload": wl, "kernel": kname, "short": short(kname), "nr": nr, "nz": nz, "members": ML, "members_in_batch": M, "operator": op,
                "dispatches": len(fv[kname]["FETCH_SIZE"]), **fmeta[kname],
                "FETCH_SIZE_kib": fetch, "fetch_calibration": cal, "fetch_correction": corr, "load_width_B": width,
                "read_bytes": read_bytes, "read_bytes_bounds": {"tally": fetch * 1024.0, "twice_tally": 2048.0 * fetch,

@@ -13,6 +13,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace xee;
@@ -88,7 +89,7 @@ int set_option_in(SweepOpts& o, int& sync_checks, int& exact_serial, const char*
 {
     struct Ent { const char* key; int* p; int lo, hi; };
     const Ent tab[] = {{"tb_T", &o.T, 1, tb_max_T()}, {"kernel", &o.kernel, 0, 3}, {"q_exact_only", &o.q_exact_only, 0, 1},
-                       {"elision", &o.elision, 0, 1}, {"tile", &o.tile, 0, 9999}, {"graph_blocks", &o.graph_blocks, 0, 8}, {"graph_events", &o.graph_events, 0, 1}, {"sync_checks", &sync_checks, 0, 1},
+                       {"elision", &o.elision, 0, 1}, {"tile", &o.tile, 0, 9999}, {"graph_blocks", &o.graph_blocks, 0, 8}, {"split_halves", &o.split_halves, 0, 1}, {"graph_events", &o.graph_events, 0, 1}, {"sync_checks", &sync_checks, 0, 1},
                        {"exact_sum_serial", &exact_serial, 0, 1}};
     if (!key) return fail(XEE_ERR_INVALID_ARGUMENT, "null option key");
     for (const Ent& t : tab)
@@ -162,6 +163,12 @@ struct xee_ensemble {
     MemberState* gst_view = nullptr;
     hipEvent_t gevE[24] = {}, gevF[24] = {};
     int g_slots = 0;                   // slots the ring was allocated for
+    // Large batches are solved as TWO halves of the member range, each on its own sweep / check streams and host thread
+    // (xee_ensemble_solve): the tail of one half's launch -- 7,744 tiles are 15.1 rounds of the 512 workgroups the GPU holds --
+    // is filled by the other half's.  A half is a VIEW: its plane pointers point into this ensemble's (non-owned), its
+    // streams, events, slots and norm workspaces are its own.
+    bool is_view = false;
+    xee_ensemble* half[2] = {nullptr, nullptr};
     float* aos_stage = nullptr;        // Tier 1: device staging of the reference's AoS coe(9,nx,ny), kept with the ensemble
     int win_first = 0, win_count = 0;  // member window of the forcing_* / field_save / field_restore calls (0 = all members)
     MemberState* st_view = nullptr;    // 4 x members: the sweeps' VIEWS of the member states in the pipelined driver.  The
@@ -422,6 +429,14 @@ int xee_ensemble_destroy(xee_ensemble_t* e)
     if (!e) return XEE_OK;
     hipSetDevice(e->device);
     if (e->stream) hipStreamSynchronize(e->stream);
+    for (auto& h : e->half) if (h) { xee_ensemble_destroy(h); h = nullptr; }
+    if (e->is_view) {
+        // what a view does not own: the planes of the ensemble it looks into, its member states, counters and host arrays
+        e->A = e->B = e->C = e->bc = e->f = e->psi[0] = e->psi[1] = e->sA = e->sB = e->sC = e->coe = e->res = nullptr;
+        e->eta = e->u = e->w = e->Q = e->terms = e->ra = e->za = e->rcuva = e->rho = e->exner = nullptr;
+        e->base = nullptr; e->st = nullptr; e->st_host = nullptr; e->ex_slow = nullptr; e->redo = nullptr; e->uv_differs = nullptr;
+        e->sums_host = nullptr; e->sx_ws = nullptr;
+    }
     for (float* p : {e->A, e->B, e->C, e->bc, e->f, e->psi[0], e->psi[1], e->sA, e->sB, e->sC, e->coe, e->res,
                      e->eta, e->u, e->w, e->Q, e->terms, e->ra, e->za, e->rcuva, e->rho, e->exner, e->sums})
         if (p) hipFree(p);
@@ -797,7 +812,8 @@ int solve_pipelined(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float 
     std::vector<int> stop_slot(g.members, -1);    // snapshot slot holding a stopped member's result
     std::vector<char> active(g.members, 1);
     e->timing = xee_timing_t{};
-    HIPCHK(hipMemsetAsync(e->redo, 0, 2 * sizeof(int), s));   // the solve's diagnostic counters
+    e->timing.sweep_streams = 1;
+    if (!e->is_view) HIPCHK(hipMemsetAsync(e->redo, 0, 2 * sizeof(int), s));   // the solve's diagnostic counters (a view: its parent did)
     HIPCHK(hipEventRecord(e->ev[0], s));
     int cnt = 0, k = 0;                           // k = number of checks enqueued
     int digested = 0;                             // ... and of checks whose outcome the host has looked at
@@ -1042,6 +1058,7 @@ int solve_graphed(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float al
     std::vector<int> stop_slot(g.members, -1);
     std::vector<char> active(g.members, 1);
     e->timing = xee_timing_t{};
+    e->timing.sweep_streams = 1;
     HIPCHK(hipMemsetAsync(e->redo, 0, 2 * sizeof(int), s));
     HIPCHK(hipEventRecord(e->ev[0], s));
     int cnt = 0, k = 0, digested = 0;
@@ -1210,6 +1227,40 @@ int solve_graphed(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float al
     return XEE_OK;
 }
 
+
+// The view of members [m0, m0 + n) of `e` for one of the two concurrent halves of a large batch's solve (created once, kept).
+int make_half_view(xee_ensemble* e, int h, int m0, int n)
+{
+    if (e->half[h] && e->half[h]->g.members == n) return XEE_OK;
+    if (e->half[h]) { xee_ensemble_destroy(e->half[h]); e->half[h] = nullptr; }
+    xee_ensemble* s = new xee_ensemble();
+    s->is_view = true;
+    s->device = e->device;
+    s->g = e->g;
+    s->g.members = n;
+    s->g.kstride = (size_t)e->g.members * e->g.plane;
+    e->half[h] = s;
+    if (create_stream(&s->stream, true) != hipSuccess) return fail(XEE_ERR_HIP, "hipStreamCreate (half) failed");
+    s->own_stream = true;
+    for (auto& ev : s->ev) HIPCHK(hipEventCreate(&ev));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&s->sums), sizeof(float) * n));
+    HIPCHK(hipMalloc(&s->ex_ws, exact_ws_bytes(s->g)));
+    s->rec.assign(n, xee_case_record_t{});
+    (void)m0;
+    return XEE_OK;
+}
+
+// (re)point a half at its member range and copy the settings of this solve
+void aim_half_view(xee_ensemble* e, xee_ensemble* s, int m0)
+{
+    const size_t off = (size_t)m0 * e->g.plane;
+    s->f = e->f + off; s->psi[0] = e->psi[0] + off; s->psi[1] = e->psi[1] + off; s->res = e->res + off; s->bc = e->bc + off;
+    s->coe = e->coe + off; s->base = e->base ? e->base + off : nullptr;
+    s->st = e->st + m0; s->st_host = e->st_host + m0; s->ex_slow = e->ex_slow + m0; s->redo = e->redo;
+    s->cur = e->cur; s->opts = e->opts; s->have_base = e->have_base; s->base_baro = e->base_baro; s->uv = e->uv;
+    s->exact_serial = e->exact_serial; s->sync_checks = e->sync_checks;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1251,6 +1302,44 @@ int xee_ensemble_solve(xee_ensemble_t* e, int max_iter, int check_step, int conv
         bool ran = false;
         if (small && e->opts.graph_blocks && tb_T > 1 && cs > tb_T && max_iter / cs >= 64 && s != nullptr)
             XCHK(solve_graphed(e, max_iter, cs, cp, alpha, tb_T, &ran));
+        // a large batch that runs on k_sweep_q alone (no single-iteration launches): two halves of the member range, side by side
+        const bool q_only = e->have_base && (e->opts.kernel == 0 || e->opts.kernel == 3) && tb_T > 1 && cs % tb_T != 1 &&
+                            (max_iter % cs) % tb_T != 1 && g.plane * sizeof(float) < ((size_t)1 << 31);
+        if (!ran && !small && q_only && e->opts.split_halves && g.members >= 2 && max_iter > 0 && s != nullptr && !e->is_view) {
+            const int n0 = (g.members + 1) / 2, n1 = g.members - n0;
+            XCHK(make_half_view(e, 0, 0, n0));
+            XCHK(make_half_view(e, 1, n0, n1));
+            aim_half_view(e, e->half[0], 0);
+            aim_half_view(e, e->half[1], n0);
+            HIPCHK(hipMemsetAsync(e->redo, 0, 2 * sizeof(int), s));
+            HIPCHK(hipStreamSynchronize(s));                     // first guess, states and counters are in place
+            int st2[2] = {XEE_OK, XEE_OK};
+            std::string msg[2];
+            auto work = [&](int h) {
+                if (hipSetDevice(e->device) != hipSuccess) { st2[h] = XEE_ERR_HIP; msg[h] = "hipSetDevice failed"; return; }
+                st2[h] = solve_pipelined(e->half[h], max_iter, cs, cp, alpha, tb_T);
+                if (st2[h] != XEE_OK) msg[h] = g_err;
+            };
+            std::thread other(work, 1);
+            work(0);
+            other.join();
+            for (int h = 0; h < 2; ++h) if (st2[h] != XEE_OK) return fail(st2[h], "solve (half " + std::to_string(h) + "): " + msg[h]);
+            if (e->half[0]->cur != e->half[1]->cur) return fail(XEE_ERR_HIP, "the two halves of the batch ended in different planes");
+            e->cur = e->half[0]->cur;
+            e->last_sweep = e->half[0]->last_sweep;
+            e->timing = e->half[0]->timing;
+            const xee_timing_t& t1 = e->half[1]->timing;
+            e->timing.solve_ms = std::max(e->timing.solve_ms, t1.solve_ms);
+            e->timing.sweep_ms = std::max(e->timing.sweep_ms, t1.sweep_ms);   // the halves' sweeps run side by side
+            e->timing.sweep_launches += t1.sweep_launches; e->timing.tiles += t1.tiles; e->timing.check_launches += t1.check_launches;
+            e->timing.sweep_streams = 2;
+            {
+                int n[2] = {0, 0};
+                HIPCHK(hipMemcpy(n, e->redo, sizeof(n), hipMemcpyDeviceToHost));
+                e->timing.redo_tiles = n[0]; e->timing.inline_redo_tiles = n[1];
+            }
+            ran = true;
+        }
         if (!ran) XCHK(solve_pipelined(e, max_iter, cs, cp, alpha, tb_T));
         for (int m = 0; m < g.members; ++m) {
             xee_case_record_t& r = e->rec[m];
@@ -1263,6 +1352,7 @@ int xee_ensemble_solve(xee_ensemble_t* e, int max_iter, int check_step, int conv
     }
 
     e->timing = xee_timing_t{};
+    e->timing.sweep_streams = 1;
     HIPCHK(hipMemsetAsync(e->redo, 0, 2 * sizeof(int), s));
     HIPCHK(hipEventRecord(e->ev[0], s));
     bool block_open = false;
@@ -1372,6 +1462,7 @@ int xee_ensemble_solve_sor(xee_ensemble_t* e, int max_iter, int check_step, int 
     if (!(flags & XEE_SOLVE_KEEP_PSI)) { launch_copy2(g, e->bc, e->psi[0], e->psi[1], s); e->cur = 0; }
     launch_state_init(g, e->st, s);
     e->timing = xee_timing_t{};
+    e->timing.sweep_streams = 1;
     e->last_sweep = SweepDesc{(e->have_base && e->opts.kernel != 1) ? (e->base_baro ? "k_sor_base<red/black>" : "k_sor_base<4 colours>") : "k_sor_color", 1, g.nx, g.ny};
     HIPCHK(hipEventRecord(e->ev[0], s));
     bool all_done = (max_iter == 0);
@@ -1631,6 +1722,7 @@ int tier1_reset(xee_ensemble* e)
     e->win_first = e->win_count = 0;
     e->first_case_id = 0;
     e->timing = xee_timing_t{};
+    e->timing.sweep_streams = 1;
     e->last_sweep = SweepDesc{};
     e->sx_slow.clear();
     e->rec.assign(e->g.members, xee_case_record_t{});

@@ -20,6 +20,8 @@ struct Grid {
     int pitch;       // floats per row, multiple of 64
     int members;     // ensemble members resident on this device
     size_t plane;    // floats per member per field = pitch * ny
+    size_t kstride;  // floats between planes k and k + 1 of the SoA fields (coe, base); 0 = members * plane.  Non-zero in the
+                     // view of a member sub-range that xee_ensemble_solve hands to one of its two sweep streams (k_sweep_q only)
 };
 
 // per-member solver state, owned by the device between checks
@@ -91,6 +93,8 @@ struct SweepOpts {
     int elision = 1;       // "elision": k_sweep_tb skips coefficient planes that are uniform over the batch
     int tile = 0;          // "tile": NW*100 + R (waves x rows per lane), 0 = the kernel's default
     int graph_blocks = 8;  // "graph_blocks": check blocks per graph for small batches (solve_graphed), 1..8; 0: one block at a time
+    int split_halves = 1;  // "split_halves": a large batch is solved as two halves of its member range side by side (two sweep
+                           //                 streams, two host threads), so that one half's launches fill the other's tails
     int graph_events = 0;  // "graph_events": 1 = an external event record per block inside the graph (its check starts at once);
                            //                 0 = one record behind the graph (the checks of a graph start when it has ended): default,
                            //                 121.8 against 126.7 ms per 100,000 iterations of one 1024x512 case (profiles/r03)

@@ -632,7 +632,7 @@ __device__ __forceinline__ TileGeom make_geom(const Grid& g, int T, int bx, int 
     tg.vx = (tg.lane >= T || tg.x0 <= 0) && (tg.lane < 64 - T || tg.x0 + 63 >= g.nx - 1);
     tg.inner = tg.x0 >= 1 && tg.x0 + 63 <= g.nx - 2 && tg.y0 >= 1 && tg.y0 + H - 1 <= g.ny - 2;
     tg.mo = (size_t)m * g.plane;
-    tg.ks = (size_t)g.members * g.plane;
+    tg.ks = g.kstride ? g.kstride : (size_t)g.members * g.plane;
     tg.stamps = nullptr;
     return tg;
 }
