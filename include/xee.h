@@ -361,6 +361,50 @@ int xee_quotient_selfcheck(int device, uint64_t seed, int blocks, int per_thread
                            uint64_t *mismatches, float *first_bad /* 2: a, d of one failing pair */);
 
 /* ---------------------------------------------------------------------------------------------
+ * The LEGACY program as ONE call: src/old-diagnose/diagnose.f90:283-841, TENDENCY mode -- source
+ * terms, Stage I -> II -> III (up to six chi solves), integral check, exchange conversion, efficiency.txt -- for a batch of
+ * cases that share grid, mode and solver lines.  The stage order lives in csrc/xee_legacy.hip and nowhere else: the Fortran
+ * host bin/xee-old-diagnose and the Python driver legacy_diagnose.py both call this.  Solver lines: strategy 1 (stop when
+ * err_now < r at a check) or 2 (|ratio| < r, ten passes); max_iter a multiple of 100.  Defined where the legacy program has
+ * undefined behaviour: Q, F are (nr-1,nz-1) B-cell fields as given; m2 in its intended form; the
+ * "w/ boundary" sums are 0 without a chi boundary field.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct xee_legacy xee_legacy_t;
+typedef struct {
+    int   geometry;        /* 0 CYLINDRICAL, 1 SPHERICAL */
+    int   density_mode;    /* 0 DENSITY_NORMAL, 1 DENSITY_BOUSSINESQ */
+    float domain[4];       /* as xee_profiles */
+    float testing_dt;      /* :489 */
+    int   op_mode;         /* 0 BAROTROPIC, 1 BAROCLINIC, 2 BARO_ALL: which of L(B=0), L(B0+dB) Stage III and the checks use */
+    int   psi_strategy;  float psi_r;  int psi_max_iter;  float psi_alpha;     /* the rpsi solver line (:147-151) */
+    int   chi_strategy;  float chi_r;  int chi_max_iter;  float chi_alpha;     /* the rchi solver line */
+    int   legacy_int;      /* exchange conversion with the program's INTEGER r, dr, dz (:1146); 0: real metric factors */
+    int   chained;         /* first guesses carried from solve to solve as the program does (:545); 0: every solve from its own start */
+    int   device;          /* -1: the current device */
+    int   first_case_id;
+} xee_legacy_config_t;
+/* A, B, C: n_cases planes (nr,nz); Q, F: n_cases planes (nr-1,nz-1); psi_bc, chi_bc: n_cases planes (nr,nz) or NULL */
+int xee_legacy_run(xee_legacy_t **result, const xee_legacy_config_t *cfg, int nr, int nz, int n_cases,
+                   const float *A, const float *B, const float *C, const float *Q, const float *F,
+                   const float *psi_bc, const float *chi_bc);
+int xee_legacy_destroy(xee_legacy_t *result);
+/* the files the legacy program writes (same names, shapes (n1,n2) with n1 contiguous), in the order they were produced */
+int xee_legacy_field_count(const xee_legacy_t *result, int *n);
+int xee_legacy_field_info(const xee_legacy_t *result, int index, char *name, int name_len, int *n1, int *n2);
+int xee_legacy_field(const xee_legacy_t *result, int icase, const char *name, float *out);
+/* the scalars behind efficiency.txt: sum_Q, sum_dtheta_dt, sum_Qeta_<op>_<rhs>, sum_wtheta_<op>_JF, sum_bndconv[2]_<op> */
+int xee_legacy_scalar_count(const xee_legacy_t *result, int *n);
+int xee_legacy_scalar_info(const xee_legacy_t *result, int index, char *key, int key_len);
+int xee_legacy_scalar(const xee_legacy_t *result, int icase, const char *key, float *value);
+/* (iterations, final residue) of every solve of the case, in the program's order ("Relaxation uses N steps ...") */
+int xee_legacy_relax(const xee_legacy_t *result, int icase, int *n_solves, int *iters, float *err_now, int capacity);
+int xee_legacy_record(const xee_legacy_t *result, int icase, xee_case_record_t *rec);
+/* efficiency.txt (:779-841, every label; numbers as ES16.9 so that an fp32 value survives the round trip) */
+int xee_legacy_efficiency_text(const xee_legacy_t *result, int icase, double elapsed_s, char *text, int text_len);
+/* every file of the case under its legacy name, and efficiency.txt, into `directory` */
+int xee_legacy_write_outputs(const xee_legacy_t *result, int icase, const char *directory, double elapsed_s);
+
+/* ---------------------------------------------------------------------------------------------
  * Multi-GPU: one process per GPU, cases partitioned in consecutive blocks, ONE collective -- an all-gather of the
  * 128-byte case records over RCCL/xGMI (SURVEY.md 8b "xee_gather_scalars", 8e "ncclAllGather").  The reference has no
  * counterpart (it is a single-threaded CPU program); this is how an ensemble host collects the per-case scalars.

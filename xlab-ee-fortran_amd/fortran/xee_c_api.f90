@@ -20,6 +20,22 @@ type, bind(C) :: xee_case_record
     real(c_float)      :: scalars(23)
 end type
 
+! xee_legacy_config_t (include/xee.h): the legacy program's mode, domain and solver lines
+type, bind(C) :: xee_legacy_config
+    integer(c_int) :: geometry, density_mode
+    real(c_float)  :: domain(4), testing_dt
+    integer(c_int) :: op_mode
+    integer(c_int) :: psi_strategy
+    real(c_float)  :: psi_r
+    integer(c_int) :: psi_max_iter
+    real(c_float)  :: psi_alpha
+    integer(c_int) :: chi_strategy
+    real(c_float)  :: chi_r
+    integer(c_int) :: chi_max_iter
+    real(c_float)  :: chi_alpha
+    integer(c_int) :: legacy_int, chained, device, first_case_id
+end type
+
 interface
     function xee_device_count(n) bind(C, name="xee_device_count") result(st)
         import :: c_int
@@ -310,6 +326,49 @@ interface
         integer(c_int) :: st
     end function
     ! frees the device ensemble the Tier-1 calls of this thread keep between calls (include/xee.h)
+    function xee_legacy_run(res, cfg, nr, nz, n_cases, A, B, C, Q, F, psi_bc, chi_bc) bind(C, name="xee_legacy_run") result(st)
+        import :: c_int, c_ptr, c_float, xee_legacy_config
+        type(c_ptr), intent(out) :: res
+        type(xee_legacy_config), intent(in) :: cfg
+        integer(c_int), value :: nr, nz, n_cases
+        real(c_float), intent(in) :: A(*), B(*), C(*), Q(*), F(*)
+        type(c_ptr), value :: psi_bc, chi_bc              ! (nr,nz) planes per case, or c_null_ptr
+        integer(c_int) :: st
+    end function
+
+    function xee_legacy_destroy(res) bind(C, name="xee_legacy_destroy") result(st)
+        import :: c_int, c_ptr
+        type(c_ptr), value :: res
+        integer(c_int) :: st
+    end function
+
+    function xee_legacy_relax(res, icase, n_solves, iters, err_now, capacity) bind(C, name="xee_legacy_relax") result(st)
+        import :: c_int, c_ptr
+        type(c_ptr), value :: res, iters, err_now         ! (this form: query the count with null arrays)
+        integer(c_int), value :: icase, capacity
+        integer(c_int), intent(out) :: n_solves
+        integer(c_int) :: st
+    end function
+
+    function xee_legacy_relax_get(res, icase, n_solves, iters, err_now, capacity) bind(C, name="xee_legacy_relax") result(st)
+        import :: c_int, c_ptr, c_float
+        type(c_ptr), value :: res
+        integer(c_int), value :: icase, capacity
+        integer(c_int), intent(out) :: n_solves
+        integer(c_int), intent(out) :: iters(*)
+        real(c_float), intent(out) :: err_now(*)
+        integer(c_int) :: st
+    end function
+
+    function xee_legacy_write_outputs(res, icase, directory, elapsed_s) bind(C, name="xee_legacy_write_outputs") result(st)
+        import :: c_int, c_ptr, c_char, c_double
+        type(c_ptr), value :: res
+        integer(c_int), value :: icase
+        character(kind=c_char), intent(in) :: directory(*)
+        real(c_double), value :: elapsed_s
+        integer(c_int) :: st
+    end function
+
     function xee_tier1_release() bind(C, name="xee_tier1_release") result(st)
         import :: c_int
         integer(c_int) :: st

@@ -11,9 +11,10 @@ src/old-diagnose/diagnose.f90:283-841 (TENDENCY mode).
     exchange conversion  methods 1 and 2 :730-772
     efficiency.txt       :779-841, every label (readable by xee_tools.read_efficiency / the reference's XEffReader)
 
-Every numerical step is a libxee call (include/xee.h): the solves run as one device-resident ensemble whose members are
-the cases of the batch (each stops on its own criterion), the O(N) stencils through the Tier-1 entry points.  This module
-is host-side orchestration only; there is no CPU fallback (libxee raises without a GPU).
+The stage order lives in libxee itself -- xee_legacy_run, csrc/xee_legacy.hip, which the Fortran host bin/xee-old-diagnose
+calls too -- where the solves run as one device-resident ensemble whose members are the cases of the batch (each stops on
+its own criterion) and the O(N) stencils go through the Tier-1 entry points.  This module packs numpy arrays into that call
+and unpacks its result; there is no CPU fallback (libxee raises without a GPU).
 
 First guesses.  `chained=True` (default) is the program's own order -- rchi / rpsi are carried from one solve to the next
 ("the order ... is such that the initial guessing field is better", :545) -- and reproduces the legacy binary's files bit
@@ -30,6 +31,7 @@ reproduce a legacy run pass `sheared(record)`: the program reads nr x nz records
 intended form; the "w/ boundary" sums are 0 without a chi boundary file; `legacy_int=True` keeps the program's INTEGER
 r, dr, dz in the exchange conversion (False: the documented fix with real metric factors).
 """
+import ctypes as C
 import os
 import time
 
@@ -38,7 +40,6 @@ import numpy as np
 from . import xee as X
 
 f32 = np.float32
-G0, THETA0 = f32(9.8), f32(298.0)          # xtt-lib-fortran/constants.f90:4
 
 
 def sheared(record, nr, nz):
@@ -48,15 +49,38 @@ def sheared(record, nr, nz):
     return np.ascontiguousarray(flat[: (nr - 1) * (nz - 1)].reshape(nz - 1, nr - 1))
 
 
-def _solver_args(spec):
-    strategy, r, max_iter, alpha = spec
-    if max_iter % 100:
-        raise ValueError("max_iter must be a multiple of the check step (100), as the legacy loop assumes")
-    if strategy == 1:
-        return dict(max_iter=int(max_iter), r1=float(r), r2=-1.0, alpha=float(alpha), converge_time=1, lost_rate=5)
-    if strategy == 2:
-        return dict(max_iter=int(max_iter), r1=-1.0, r2=float(r), alpha=float(alpha), converge_time=10, lost_rate=5)
-    raise ValueError("legacy strategies 3 and 4 (max norm over the whole array) are not supported")
+class _Config(C.Structure):
+    """xee_legacy_config_t (include/xee.h)"""
+    _fields_ = [("geometry", C.c_int), ("density_mode", C.c_int), ("domain", C.c_float * 4), ("testing_dt", C.c_float),
+                ("op_mode", C.c_int),
+                ("psi_strategy", C.c_int), ("psi_r", C.c_float), ("psi_max_iter", C.c_int), ("psi_alpha", C.c_float),
+                ("chi_strategy", C.c_int), ("chi_r", C.c_float), ("chi_max_iter", C.c_int), ("chi_alpha", C.c_float),
+                ("legacy_int", C.c_int), ("chained", C.c_int), ("device", C.c_int), ("first_case_id", C.c_int)]
+
+
+def _lib():
+    L = X.lib()
+    if not getattr(L, "_legacy_bound", False):
+        vp, fp = C.c_void_p, np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+        L.xee_legacy_run.argtypes = [C.POINTER(vp), C.POINTER(_Config), C.c_int, C.c_int, C.c_int, fp, fp, fp, fp, fp, vp, vp]
+        L.xee_legacy_destroy.argtypes = [vp]
+        L.xee_legacy_field_count.argtypes = [vp, C.POINTER(C.c_int)]
+        L.xee_legacy_field_info.argtypes = [vp, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.xee_legacy_field.argtypes = [vp, C.c_int, C.c_char_p, fp]
+        L.xee_legacy_scalar_count.argtypes = [vp, C.POINTER(C.c_int)]
+        L.xee_legacy_scalar_info.argtypes = [vp, C.c_int, C.c_char_p, C.c_int]
+        L.xee_legacy_scalar.argtypes = [vp, C.c_int, C.c_char_p, C.POINTER(C.c_float)]
+        L.xee_legacy_relax.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_int]
+        L.xee_legacy_record.argtypes = [vp, C.c_int, C.c_void_p]
+        L.xee_legacy_efficiency_text.argtypes = [vp, C.c_int, C.c_double, C.c_char_p, C.c_int]
+        L.xee_legacy_write_outputs.argtypes = [vp, C.c_int, C.c_char_p, C.c_double]
+        L._legacy_bound = True
+    return L
+
+
+def _chk(status):
+    if status != 0:
+        raise X.XeeError(status, (X.lib().xee_last_error() or b"").decode())
 
 
 def run(cases, *, geometry=0, density_mode=0, domain=(0.0, 1.0, 0.0, 1.0), testing_dt=100.0, operator="BARO_ALL",
@@ -64,183 +88,100 @@ def run(cases, *, geometry=0, density_mode=0, domain=(0.0, 1.0, 0.0, 1.0), testi
         first_case_id=0):
     """cases: list of dict(A, B, C (nz,nr) O-grid planes; Q, F (nz-1,nr-1) B cells; optional psi_bc, chi_bc (nz,nr)) --
     all with or all without each boundary field.  Returns a list (one per case) of
-    dict(files={legacy file name: array}, scalars, relax=[(iterations, err_now)], lines=[(label, value, ratio)], record)."""
+    dict(files={legacy file name: array}, scalars, relax=[(iterations, err_now)], lines=[(label, value, ratio)], record).
+    The stage order itself is xee_legacy_run's (csrc/xee_legacy.hip); this function packs the arrays and unpacks the result."""
+    L = _lib()
     M = len(cases)
     nz, nr = cases[0]["A"].shape
-    has_psi_bc = cases[0].get("psi_bc") is not None
-    has_chi_bc = cases[0].get("chi_bc") is not None
-    bt = operator in ("BAROTROPIC", "BARO_ALL")
-    bcl = operator in ("BAROCLINIC", "BARO_ALL")
-    prof = X.profiles(nr, nz, geometry, density_mode, domain)
-    sin_t = prof["sin_table"] if geometry == 1 else None
-    stack = lambda key: np.stack([np.ascontiguousarray(c[key], f32) for c in cases])
+    stack = lambda key: np.ascontiguousarray(np.stack([np.ascontiguousarray(c[key], f32) for c in cases]))
     A, B, Cc, Q, F = (stack(k) for k in ("A", "B", "C", "Q", "F"))
-    zero_O = np.zeros((M, nz, nr), f32)
-    out = [dict(files={}, scalars={}, relax=[]) for _ in range(M)]
-    psi_args, chi_args = _solver_args(psi_solver), _solver_args(chi_solver)
-
-    with X.Ensemble(nr, nz, M, device=device) as ens:
-        ens.set_profiles(prof)
-        ens.set_case_ids(first_case_id)
-        ens.upload("A", A); ens.upload("B", B); ens.upload("C", Cc); ens.upload("Q", Q)
-        ens.assemble(X.BAROCLINIC)                      # K1 (:289-312) + the full-B stencil of Stage I (:449)
-        sA, sB, sC = ens.download("SOLVER_A"), ens.download("SOLVER_B"), ens.download("SOLVER_C")
-
-        # ---- source terms and the fields Stage II needs, per case (O(N) stencils, Tier 1)
-        pre = []
+    psi_bc = stack("psi_bc") if cases[0].get("psi_bc") is not None else None
+    chi_bc = stack("chi_bc") if cases[0].get("chi_bc") is not None else None
+    cfg = _Config()
+    cfg.geometry, cfg.density_mode, cfg.testing_dt = int(geometry), int(density_mode), float(testing_dt)
+    for k, v in enumerate(domain):
+        cfg.domain[k] = float(v)
+    cfg.op_mode = {"BAROTROPIC": 0, "BAROCLINIC": 1, "BARO_ALL": 2}[operator]
+    cfg.psi_strategy, cfg.psi_r, cfg.psi_max_iter, cfg.psi_alpha = int(psi_solver[0]), float(psi_solver[1]), int(psi_solver[2]), float(psi_solver[3])
+    cfg.chi_strategy, cfg.chi_r, cfg.chi_max_iter, cfg.chi_alpha = int(chi_solver[0]), float(chi_solver[1]), int(chi_solver[2]), float(chi_solver[3])
+    cfg.legacy_int, cfg.chained, cfg.device, cfg.first_case_id = int(bool(legacy_int)), int(bool(chained)), int(device), int(first_case_id)
+    for spec in (psi_solver, chi_solver):
+        if spec[2] % 100:
+            raise ValueError("max_iter must be a multiple of the check step (100), as the legacy loop assumes")
+        if spec[0] not in (1, 2):
+            raise ValueError("legacy strategies 3 and 4 (max norm over the whole array) are not supported")
+    h = C.c_void_p()
+    ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+    _chk(L.xee_legacy_run(C.byref(h), C.byref(cfg), nr, nz, M, A, B, Cc, Q, F, ptr(psi_bc), ptr(chi_bc)))
+    try:
+        n = C.c_int()
+        _chk(L.xee_legacy_field_count(h, C.byref(n)))
+        fields = []
+        for k in range(n.value):
+            name, n1, n2 = C.create_string_buffer(96), C.c_int(), C.c_int()
+            _chk(L.xee_legacy_field_info(h, k, name, 96, C.byref(n1), C.byref(n2)))
+            fields.append((name.value.decode(), n1.value, n2.value))
+        _chk(L.xee_legacy_scalar_count(h, C.byref(n)))
+        keys = []
+        for k in range(n.value):
+            key = C.create_string_buffer(96)
+            _chk(L.xee_legacy_scalar_info(h, k, key, 96))
+            keys.append(key.value.decode())
+        prof = X.profiles(nr, nz, geometry, density_mode, domain)
+        out = []
         for m in range(M):
-            rhoA_A, rhoB_C, rhoB_B, rhoC_C = X.legacy_averages(A[m], B[m], Cc[m])           # :329-354
-            m2 = X.m2_from_C(rhoC_C, prof, sin_t)                                            # :359-380
-            JJ = X.JJ_B(Q[m], prof["exner"])                                                 # :383-387
-            thm = X.rhs_thermal(Q[m], prof["ra"], prof["exner"])                             # :395-406
-            mom = X.rhs_momentum(m2, F[m], prof)                                             # :412-436
-            pre.append(dict(rhoA_A=rhoA_A, rhoB_C=rhoB_C, rhoB_B=rhoB_B, JJ=JJ, f_psi=X.add_fields(thm, mom)))
-            fl = out[m]["files"]
-            fl["J-B.bin"], fl["RHS_rpsi_thm-O.bin"], fl["RHS_rpsi_mom-O.bin"] = JJ, thm, mom
-            fl["solver_a-sA.bin"], fl["solver_b-B.bin"], fl["solver_c-sC.bin"] = sA[m], sB[m], sC[m]
-            out[m]["scalars"]["sum_Q"] = X.integrate_weight_B(Q[m], prof)                    # :284
-        f_psi = np.stack([p["f_psi"] for p in pre])
-        psi_start = stack("psi_bc") if has_psi_bc else zero_O
-
-        def solve(args, start=None):
-            """one solve_elliptic on every case; start None = carry the current field on (the program's chaining)"""
-            a = dict(args)
-            if start is not None:
-                ens.upload("BC_INIT", start)
-            rec = ens.solve(a.pop("max_iter"), a.pop("r1"), a.pop("r2"), a.pop("alpha"),
-                            flags=X.SOLVE_DEFAULT if start is not None else X.SOLVE_KEEP_PSI, **a)
-            for m in range(M):
-                out[m]["relax"].append((int(rec["iters"][m]), f32(rec["err_now"][m])))
-            return ens.download("PSI")
-
-        # ---- Stage I (:449-463)
-        ens.upload("FORCING", f_psi)
-        rpsi = solve(psi_args, psi_start)
-        ens.cal_uw()                                                                          # rpsiToUW :915-941
-        U, W = ens.download("U"), ens.download("W")
-        # ---- Stage II (:468-518), per case
-        theta, b_anom, sb_anom = [], [], []
-        for m in range(M):
-            fl, p = out[m]["files"], pre[m]
-            fl["rpsi_before-O.bin"], fl["w_before-A.bin"], fl["u_before-C.bin"] = rpsi[m], W[m], U[m]
-            dth = X.theta_tendency(p["JJ"], p["rhoA_A"], W[m], p["rhoB_C"], U[m])             # :470-479
-            fl["dtheta_dt-B.bin"] = dth
-            out[m]["scalars"]["sum_dtheta_dt"] = X.integrate_weight_B(dth, prof)              # :487
-            upd = X.theta_anomaly_update(dth, testing_dt, p["rhoB_B"], p["rhoA_A"], p["rhoB_C"], prof)   # :489-518
-            fl["theta_after-B.bin"] = upd["theta"]
-            theta.append(upd["theta"]); b_anom.append(upd["b_anomaly"]); sb_anom.append(upd["solver_b_anomaly"])
-        # ---- Stage III right-hand sides (:523-541)
-        f_basic = np.stack([X.rhs_from_B(pre[m]["rhoB_B"]) for m in range(M)])                # b_basic_B = rhoB_B (:348)
-        f_anom = np.stack([X.rhs_from_B(b_anom[m]) for m in range(M)])
-        for m in range(M):
-            out[m]["files"]["RHS_rchi-O.bin"] = X.add_fields(f_basic[m], f_anom[m])           # :540
-        sb_B0dB = np.stack([X.add_fields(sB[m], sb_anom[m]) for m in range(M)])               # :572
-
-        def set_operator(name):
-            if name == "0":
-                ens.assemble_solver(False)                                                    # solverB_B = 0 (:553)
-            else:
-                ens.upload("SOLVER_B", sb_B0dB)
-                ens.assemble_solver(True)
-        ops = (["0"] if bt else []) + (["B0dB"] if bcl else [])
-
-        def chi_solve(op, rhs, f, start):
-            set_operator(op)
-            ens.upload("FORCING", f)
-            rchi = solve(chi_args, start)
-            ens.cal_eta()                                                                     # cal_eta :1129-1141
-            rec = ens.ee_scalars()                                                            # cal_sum_Qeta :1073-1092
-            eta = ens.download("ETA")
-            for m in range(M):
-                out[m]["scalars"][f"sum_Qeta_{op}_{rhs}"] = f32(rec["sum_Qeta"][m])
-                out[m]["files"][f"eta-[{op}_{rhs}]-A.bin"], out[m]["files"][f"rchi-[{op}_{rhs}]-O.bin"] = eta[m], rchi[m]
-
-        if has_chi_bc:                                                                        # :548-588
-            chi_start = stack("chi_bc")
-            for n, op in enumerate(ops):
-                chi_solve(op, "0", zero_O, chi_start if (n == 0 or not chained) else None)
-        first = True                                                                          # rchi = 0 (:590)
-        for rhs, f in (("dB", f_anom), ("B0", f_basic)):                                      # :594-673
-            for op in ops:
-                chi_solve(op, rhs, f, zero_O if (first or not chained) else None)
-                first = False
-        # ---- integral check (:679-725)
-        for n, op in enumerate(ops):
-            set_operator(op)
-            ens.upload("FORCING", f_psi)
-            rpsi = solve(psi_args, psi_start if (n == 0 or not chained) else None)
-            ens.cal_uw()
-            U, W = ens.download("U"), ens.download("W")
-            for m in range(M):
-                fl = out[m]["files"]
-                fl[f"rpsi_after-[{op}]-O.bin"], fl[f"w_after-[{op}]-A.bin"], fl[f"u_after-[{op}]-C.bin"] = rpsi[m], W[m], U[m]
-                wth = X.cal_wtheta(W[m], theta[m])                                            # :1117-1127
-                fl[f"wtheta_JF_after-[{op}]-B.bin"] = wth
-                out[m]["scalars"][f"sum_wtheta_{op}_JF"] = f32(X.integrate_weight_B(wth, prof) * (G0 / THETA0))   # :703
-        records = ens.records()
-    # ---- exchange conversion, methods 1 and 2 (:730-772)
-    if has_chi_bc:
-        for m in range(M):
-            fl, S = out[m]["files"], out[m]["scalars"]
-            for op in ops:
-                c0, cdB, cB0 = (fl[f"rchi-[{op}_{r}]-O.bin"] for r in ("0", "dB", "B0"))
-                for meth, chi_sum in (("", X.add_fields(X.add_fields(c0, cdB), cB0)), ("2", X.add_fields(cdB, cB0))):
-                    bnd, s = X.exchange_conversion(fl[f"rpsi_after-[{op}]-O.bin"], chi_sum, Cc[m], prof, legacy_int=legacy_int)
-                    fl[f"bndconv{meth}-[{op}].bin"], S[f"sum_bndconv{meth}_{op}"] = bnd, f32(s)
-    for m in range(M):
-        out[m]["lines"] = efficiency_lines(out[m]["scalars"], bt, bcl, has_chi_bc)
-        out[m]["record"] = records[m]
-        out[m]["profiles"] = prof
-    return out
+            res = dict(files={}, scalars={}, relax=[], profiles=prof)
+            for name, n1, n2 in fields:
+                arr = np.zeros((n2, n1), f32)
+                _chk(L.xee_legacy_field(h, m, name.encode(), arr))
+                res["files"][name] = arr
+            for key in keys:
+                v = C.c_float()
+                if L.xee_legacy_scalar(h, m, key.encode(), C.byref(v)) == 0:
+                    res["scalars"][key] = f32(v.value)
+            ns = C.c_int()
+            _chk(L.xee_legacy_relax(h, m, C.byref(ns), None, None, 0))
+            its, errs = np.zeros(ns.value, np.int32), np.zeros(ns.value, f32)
+            _chk(L.xee_legacy_relax(h, m, C.byref(ns), its.ctypes.data_as(C.c_void_p), errs.ctypes.data_as(C.c_void_p), ns.value))
+            res["relax"] = [(int(i), f32(e)) for i, e in zip(its, errs)]
+            rec = np.zeros(1, X.RECORD_DTYPE)
+            _chk(L.xee_legacy_record(h, m, rec.ctypes.data_as(C.c_void_p)))
+            res["record"] = rec[0]
+            buf = C.create_string_buffer(8192)
+            _chk(L.xee_legacy_efficiency_text(h, m, 0.0, buf, 8192))
+            res["efficiency_text"] = buf.value.decode()
+            res["lines"] = efficiency_lines(res["efficiency_text"])
+            out.append(res)
+        return out
+    finally:
+        L.xee_legacy_destroy(h)
 
 
-def efficiency_lines(S, bt, bcl, has_chi_bc):
-    """efficiency.txt (old-diagnose/diagnose.f90:779-841) as [(label, value, ratio | None) | ("#", comment)] in the
-    program's order; the scalar arithmetic (ratios, the decomposition sum :805,:833) is fp32 as in the program."""
-    sq = f32(S["sum_Q"])
-    g = lambda key: f32(S.get(key, 0.0))
-    out = [("sum Q                                      ", sq, None), ("sum dtheta_dt                              ", g("sum_dtheta_dt"), None),
-           ("Local heat response (sum Q / sum dtheta_dt)", g("sum_dtheta_dt") / sq, None)]      # (:784 divides dtheta by Q)
-    for on, op, present in (("B=0)   ", "0", bt), ("B=B0dB)", "B0dB", bcl)):
-        if not present:
+def efficiency_lines(text):
+    """efficiency.txt as [(label, value, ratio | None) | ("#", comment)] in the program's order, without its first line
+    (the elapsed time): parsed back from the text xee_legacy_efficiency_text wrote"""
+    out = []
+    for ln in text.splitlines()[1:]:
+        if ln.startswith(" # "):
+            out.append(("#", ln[3:]))
             continue
-        two = lambda lab, v: out.append((lab, f32(v), f32(v) / sq))
-        out.append(("#", "Boundary efficiency"))
-        if has_chi_bc:
-            two(f"eta [L({on} = 0]      w/  boundary", g(f"sum_Qeta_{op}_0"))
-        out.append(("#", "Internal efficiency"))
-        two(f"eta [L({on} = dB]     wo/ boundary", g(f"sum_Qeta_{op}_dB"))
-        two(f"eta [L({on} = B0]     wo/ boundary", g(f"sum_Qeta_{op}_B0"))
-        if has_chi_bc:
-            out.append(("#", "Boundary conversion (Method 1)"))
-            two("bndconv [L(B=0) = B0dB]   w/ boundary" if op == "0" else "bndconv [L(B=B0dB) = B0dB]w/ boundary", g(f"sum_bndconv_{op}"))
-            out.append(("#", "Boundary conversion (Method 2)"))
-            two("bndconv2 [L(B=0) = B0dB]   w/ boundary" if op == "0" else "bndconv2 [L(B=B0dB) = B0dB]w/ boundary", g(f"sum_bndconv2_{op}"))
-        out.append(("#", "Decomposition sum"))
-        tmp = f32(f32(g(f"sum_Qeta_{op}_0") + g(f"sum_Qeta_{op}_dB")) + g(f"sum_Qeta_{op}_B0"))
-        if has_chi_bc:
-            tmp = f32(tmp + g(f"sum_bndconv_{op}"))
-        two(f"etaQ [L({on} = J F] w/  boundary", tmp)
-        out.append(("#", "wtheta integral"))
-        two(f"wtheta [L({on} = J F] w/  boundary", g(f"sum_wtheta_{op}_JF"))
+        label, _, rest = ln[1:].partition(" : ")
+        parts = rest.split(" , ")
+        out.append((label, f32(float(parts[0])), f32(float(parts[1])) if len(parts) > 1 else None))
     return out
 
 
 def write_outputs(result, outdir, elapsed=None):
-    """Write one case's files under the legacy names and its efficiency.txt (ES16.9 numbers: an fp32 value round-trips;
-    the reference's list-directed output prints 8 digits)."""
+    """Write one case's files under the legacy names and its efficiency.txt (the text xee_legacy_efficiency_text made --
+    ES16.9 numbers: an fp32 value round-trips; the reference's list-directed output prints 8 digits -- with the elapsed
+    time filled in)."""
     os.makedirs(outdir, exist_ok=True)
     for name, arr in result["files"].items():
         np.ascontiguousarray(arr, f32).tofile(os.path.join(outdir, name))
+    head, _, body = result["efficiency_text"].partition("\n")
     with open(os.path.join(outdir, "efficiency.txt"), "w") as fh:
-        fh.write(" Time elapsed (sec)                          : %16.9E\n" % (0.0 if elapsed is None else elapsed))
-        for item in result["lines"]:
-            if item[0] == "#":
-                fh.write(" # %s\n" % item[1])
-            elif item[2] is None:
-                fh.write(" %s : %16.9E\n" % (item[0], float(item[1])))
-            else:
-                fh.write(" %s : %16.9E , %16.9E\n" % (item[0], float(item[1]), float(item[2])))
+        fh.write(head.partition(" : ")[0] + " : %16.9E\n" % (0.0 if elapsed is None else elapsed))
+        fh.write(body)
     return os.path.join(outdir, "efficiency.txt")
 
 
