@@ -94,6 +94,24 @@ def test_bench_two_ranks_rehearsal_over_gloo():
     assert d["value"] > 0 and d["scaling"] == "weak" and d["config"]["parallelism"] == "ensemble-dp2"
 
 
+def test_bench_sweep_workload_two_ranks_rehearsal():
+    """bench.py --workload sweep (configs[4]) with two ranks on one card over gloo: ranks own blocks of timesteps, the case
+    records of both arrive at rank 0, one JSON line with the per-stage figures"""
+    import os
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(XEE_BENCH_BACKEND="gloo", XEE_BENCH_DEVICE="0")
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--workload", "sweep", "--members", "2", "--nr", "128",
+                        "--nz", "64", "--max-iter", "300", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["cases_per_gpu"] == 12 and d["all_cases_ran_to_max_iter"] is True
+    assert d["value"] > 0 and set(d["per_stage"]) == {"BAROTROPIC/all three kinds", "BAROCLINIC/all three kinds"}
+    assert "gloo" in d["config"]["record_gather"]
+
+
 def test_cabi_record_gather_on_one_rank():
     """xee_comm_* / xee_gather_scalars (RCCL behind the C-ABI) on the one GPU of this box: a world of one rank goes through
     ncclCommInitRank and ncclAllGather for real (RCCL refuses two ranks on one device, so the N > 1 exchange itself is

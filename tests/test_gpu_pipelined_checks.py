@@ -81,6 +81,40 @@ def test_graphed_small_batch_driver(max_iter):
         assert len(set(c % 24 for c in stops)) >= 6, stops       # stops land on many slots of the ring
 
 
+@pytest.mark.parametrize("serial", [0, 1])
+def test_large_batch_split_halves_and_serial_norm(serial):
+    """A batch above the large-batch threshold (4 Mi points): by default its member range is solved as two halves side by
+    side (option split_halves), checks one deep behind the sweeps.  Nine members (halves of 5 and 4) that stop at different
+    checks; the two-halves driver, the one-stream driver and the synchronous driver give the same bits -- also with option
+    exact_sum_serial, which keeps the large batch's depth and only moves the norm onto the check stream."""
+    nr, nz, M = 1024, 512, 9
+    ins = [H.member_inputs(nr, nz, m) for m in range(M)]
+    A, B, Cc, bc = (np.stack([x[k] for x in ins]) for k in range(4))
+    # (the members' residuals decline slowly past 4.7e-3 .. 4.9e-3 at different iterations: an absolute criterion spreads the stops)
+    cfg = dict(r1=(4.9e-3 if serial else 4.74e-3), r2=-1.0, max_iter=(500 if serial else 3000), alpha=1.0)
+    outs = {}
+    for tag, opts in (("halves", {}), ("one", {"split_halves": 0}), ("sync", {"sync_checks": 1})):
+        with xee.Ensemble(nr, nz, M) as e:
+            e.set_option("exact_sum_serial", serial)
+            for kk, v in opts.items():
+                e.set_option(kk, v)
+            e.set_profiles(xee.profiles(nr, nz))
+            for name, arr in (("A", A), ("B", B), ("C", Cc), ("BC_INIT", bc)):
+                e.upload(name, arr)
+            e.forcing_from_B(); e.assemble(xee.BAROTROPIC)
+            rec = e.solve(cfg["max_iter"], cfg["r1"], cfg["r2"], cfg["alpha"], converge_time=1)
+            outs[tag] = (rec.copy(), e.download("PSI"), e.download("RESIDUAL"), e.timing())
+    ra, pa, resa, ta = outs["halves"]
+    assert ta["sweep_streams"] == 2 and outs["one"][3]["sweep_streams"] == 1
+    for tag in ("one", "sync"):
+        rb, pb, resb, _ = outs[tag]
+        assert np.array_equal(ra["iters"], rb["iters"]) and np.array_equal(ra["err_bits"], rb["err_bits"]), (tag, ra["iters"], rb["iters"])
+        assert ra["err_now"].tobytes() == rb["err_now"].tobytes() and ra["ratio"].tobytes() == rb["ratio"].tobytes(), tag
+        assert biteq(pa, pb), tag
+        assert biteq(resa[:, 1:-1, 1:-1], resb[:, 1:-1, 1:-1]), tag
+    if not serial:
+        assert len(set(int(v) for v in ra["iters"])) >= 3, ra["iters"]        # members stop at different checks
+
 def test_pipelined_other_check_steps():
     """check_step that is not a multiple of the blocked launch length, tiny converge_time."""
     nr, nz = 80, 56

@@ -1324,8 +1324,13 @@ int xee_ensemble_solve(xee_ensemble_t* e, int max_iter, int check_step, int conv
             work(0);
             other.join();
             for (int h = 0; h < 2; ++h) if (st2[h] != XEE_OK) return fail(st2[h], "solve (half " + std::to_string(h) + "): " + msg[h]);
-            if (e->half[0]->cur != e->half[1]->cur) return fail(XEE_ERR_HIP, "the two halves of the batch ended in different planes");
             e->cur = e->half[0]->cur;
+            if (e->half[1]->cur != e->cur) {
+                // (a half whose members all stopped ends early, possibly in the other ping-pong plane: its results move over)
+                HIPCHK(hipMemcpyAsync(e->psi[e->cur] + (size_t)n0 * g.plane, e->psi[e->cur ^ 1] + (size_t)n0 * g.plane,
+                                      sizeof(float) * g.plane * n1, hipMemcpyDeviceToDevice, s));
+                HIPCHK(hipStreamSynchronize(s));
+            }
             e->last_sweep = e->half[0]->last_sweep;
             e->timing = e->half[0]->timing;
             const xee_timing_t& t1 = e->half[1]->timing;
