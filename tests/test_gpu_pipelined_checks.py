@@ -84,10 +84,10 @@ def test_graphed_small_batch_driver(max_iter):
 @pytest.mark.parametrize("serial", [0, 1])
 def test_large_batch_split_halves_and_serial_norm(serial):
     """A batch above the large-batch threshold (4 Mi points): by default its member range is solved as two halves side by
-    side (option split_halves), checks one deep behind the sweeps.  Nine members (halves of 5 and 4) that stop at different
+    side (option split_halves, from 32 members on), checks one deep behind the sweeps.  33 members (halves of 17 and 16) that stop at different
     checks; the two-halves driver, the one-stream driver and the synchronous driver give the same bits -- also with option
     exact_sum_serial, which keeps the large batch's depth and only moves the norm onto the check stream."""
-    nr, nz, M = 1024, 512, 9
+    nr, nz, M = 1024, 512, 33
     ins = [H.member_inputs(nr, nz, m) for m in range(M)]
     A, B, Cc, bc = (np.stack([x[k] for x in ins]) for k in range(4))
     # (the members' residuals decline slowly past 4.7e-3 .. 4.9e-3 at different iterations: an absolute criterion spreads the stops)

@@ -1305,7 +1305,9 @@ int xee_ensemble_solve(xee_ensemble_t* e, int max_iter, int check_step, int conv
         // a large batch that runs on k_sweep_q alone (no single-iteration launches): two halves of the member range, side by side
         const bool q_only = e->have_base && (e->opts.kernel == 0 || e->opts.kernel == 3) && tb_T > 1 && cs % tb_T != 1 &&
                             (max_iter % cs) % tb_T != 1 && g.plane * sizeof(float) < ((size_t)1 << 31);
-        if (!ran && !small && q_only && e->opts.split_halves && g.members >= 2 && max_iter > 0 && s != nullptr && !e->is_view) {
+        // (measured on 1024x512 batches, tools/split_probe.py: +2 .. +4 % at 32 members, nothing at 64 and 256, a loss below 24 --
+        // the halves must themselves still be large batches)
+        if (!ran && !small && q_only && e->opts.split_halves && g.members >= 32 && max_iter > 0 && s != nullptr && !e->is_view) {
             const int n0 = (g.members + 1) / 2, n1 = g.members - n0;
             XCHK(make_half_view(e, 0, 0, n0));
             XCHK(make_half_view(e, 1, n0, n1));
