@@ -57,7 +57,7 @@ def test_committed_counters_belong_to_this_build():
     sys.path.insert(0, str(ROOT))
     import bench
     ent = bench.traffic_entry("k_sweep_q", 1024, 512, 16, "BAROTROPIC")      # (32 cases = two halves of 16 side by side)
-    assert ent and ent["bytes_per_launch"] > 3e8 and ent["SQ_ACTIVE_INST_VALU"] > 0
+    assert ent and ent["bytes_per_launch"] > 1.5e8 and ent["SQ_ACTIVE_INST_VALU"] > 0   # (16 cases: 166.8 MB compulsory)
 
 
 def test_bench_gpus2_as_a_plain_command_self_launches():
