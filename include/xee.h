@@ -58,9 +58,15 @@ int         xee_device_count(int *count);  /* number of visible HIP devices (0 i
  * choose between implementations of the same arithmetic (tests run them against each other and the oracle):
  *   "tb_T"             iterations per temporally blocked sweep launch, 1..16 (8); 1 = the streaming kernel
  *   "kernel"           0 auto | 1 nine coefficient planes (k_sweep_tb) | 2 generating planes with the IEEE
- *                      division (k_sweep_tb4) | 3 generating planes, hoisted reciprocal (k_sweep_q; auto's choice
- *                      whenever xee_ensemble_assemble / xee_cal_coe built the planes)
- *   "q_exact_only"     1: k_sweep_q runs its exact (fallback) body on every tile
+ *                      division (k_sweep_tb4) | 3 generating planes, hoisted reciprocal (k_sweep_q) | 4 as 3, with the plain
+ *                      launches streamed along z by single waves (k_sweep_z) wherever that kernel applies.  Auto is 3
+ *                      whenever xee_ensemble_assemble / xee_cal_coe built the planes, and 4 for a batch that fills the
+ *                      device with k_sweep_z (e.g. 32 cases of 1024x512): BAROTROPIC operator, alpha = 1, every member's
+ *                      |coe5| within [2^-120, 2^120] and its smallest interior |forcing| at least 2^26 times
+ *                      max(2^-100, max |coe5| 2^-120) -- tested per solve (one pass over three planes); the residual-writing
+ *                      launch of every check block stays k_sweep_q's
+ *   "z_pairs"          chunks of rows per strip of k_sweep_z, in pairs: 1..64, 0 = chosen from the batch (0)
+ *   "q_exact_only"     1: k_sweep_q / k_sweep_z run their exact (fallback) body on every tile / wave
  *   "elision"          0: k_sweep_tb loads coefficient planes even when they are uniform over the batch (1)
  *   "tile"             NW*100+R: waves x rows per lane of a blocked tile, 0 = the kernel's default
  *   "sync_checks"      1: residual checks synchronous instead of pipelined behind the sweeps (0)
@@ -281,6 +287,12 @@ typedef struct {
                                   sweep_launches counts both halves' launches (each over half the members) and sweep_ms is the
                                   longer of the two halves' sweep times -- the average duration of one launch, as a profiler
                                   sees it, is sweep_ms / (sweep_launches / sweep_streams) */
+    int64_t z_launches;        /* of sweep_launches: launches of the streaming k_sweep_z (large BAROTROPIC batches; the others of
+                                  such a solve -- the residual-writing launch of every check block and a remainder -- are
+                                  k_sweep_q's) */
+    double  z_ms;              /* device time between the first and the last k_sweep_z launch of every check block (HIP events on the
+                                  launches' stream; large batches only; two halves: the longer of the two) and the number of launches */
+    int64_t z_timed_launches;  /* between those events: one k_sweep_z launch lasts z_ms / (z_timed_launches / sweep_streams) */
 } xee_timing_t;
 
 /* flags of xee_ensemble_solve */

@@ -106,6 +106,9 @@ def test_large_batch_split_halves_and_serial_norm(serial):
             outs[tag] = (rec.copy(), e.download("PSI"), e.download("RESIDUAL"), e.timing())
     ra, pa, resa, ta = outs["halves"]
     assert ta["sweep_streams"] == 2 and outs["one"][3]["sweep_streams"] == 1
+    # the pipelined drivers stream this batch's plain launches (k_sweep_z, members leaving at different checks included); the
+    # synchronous driver is k_sweep_q throughout
+    assert ta["z_launches"] > 0 and outs["one"][3]["z_launches"] > 0 and outs["sync"][3]["z_launches"] == 0
     for tag in ("one", "sync"):
         rb, pb, resb, _ = outs[tag]
         assert np.array_equal(ra["iters"], rb["iters"]) and np.array_equal(ra["err_bits"], rb["err_bits"]), (tag, ra["iters"], rb["iters"])

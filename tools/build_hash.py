@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""sha256 over what decides the blocked sweep's counters: csrc/xee_sweepq.hip, csrc/xee_api.hip (the launch schedule),
+"""sha256 over what decides the blocked sweep's counters: csrc/xee_sweepq.hip, csrc/xee_sweepz.hip, csrc/xee_api.hip (the launch schedule),
 csrc/xee_device.h and the HIPFLAGS line of the Makefile.  tools/profile_round.sh / pmc_only.sh record it on the GPU box
 next to the PMC CSVs; tools/pmc_summarize.py stores it in profiles/traffic.json; bench.py recomputes it and quotes the
 stored counters only when the two agree.
@@ -9,7 +9,8 @@ import re
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-FILES = ("xlab-ee-fortran_amd/csrc/xee_sweepq.hip", "xlab-ee-fortran_amd/csrc/xee_api.hip", "xlab-ee-fortran_amd/csrc/xee_device.h")
+FILES = ("xlab-ee-fortran_amd/csrc/xee_sweepq.hip", "xlab-ee-fortran_amd/csrc/xee_sweepz.hip", "xlab-ee-fortran_amd/csrc/xee_api.hip",
+         "xlab-ee-fortran_amd/csrc/xee_device.h")
 
 
 def build_hash(root=ROOT):

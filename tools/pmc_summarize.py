@@ -25,7 +25,7 @@ from pathlib import Path
 SHAPES = {"ensemble": (1024, 512, 32, "BAROTROPIC"), "baroclinic": (1024, 512, 32, "BAROCLINIC"),
           "single": (1024, 512, 1, "BAROTROPIC"), "highres": (4096, 2048, 1, "BAROTROPIC")}
 # bytes per lane of the dominant kernel's global loads (decides which calibration applies)
-LOAD_WIDTH = {"k_sweep_q": 4, "k_sweep_tb4": 4, "k_sweep_tb": 4, "k_sweep_stream": 16, "k_sweep_p": 8}
+LOAD_WIDTH = {"k_sweep_z": 16, "k_sweep_q": 4, "k_sweep_tb4": 4, "k_sweep_tb": 4, "k_sweep_stream": 16, "k_sweep_p": 8}
 
 
 def read_pass(d):
@@ -53,7 +53,7 @@ def read_pass(d):
 
 
 def short(name):
-    for k in ("k_sweep_q", "k_sweep_p", "k_sweep_tb4", "k_sweep_tb", "k_sweep_stream"):
+    for k in ("k_sweep_z", "k_sweep_q", "k_sweep_p", "k_sweep_tb4", "k_sweep_tb", "k_sweep_stream"):
         if k + "<" in name:
             return k
     return None
@@ -92,16 +92,30 @@ def main():
         if corr is None:            # 8 B/lane: not separately calibrated, bracket between the two
             corr = 0.5 * (cal.get("x16", 0.5) + cal.get("x4", 0.735))
         fetch = mean(fv[kname]["FETCH_SIZE"])
-        # physical bounds of the sweep's read bytes per launch (T = 8, 64 x H tiles stepping by 64 - 2T, H - 2T)
-        T, H = 8, (64 if op == "BAROTROPIC" else 48)
-        planes = 4 if op == "BAROTROPIC" else 6
-        ntx, nty = -(-(nr - 1) // (64 - 2 * T)), -(-(nz - 1) // (H - 2 * T))
-        # members per LAUNCH: a large batch is solved as two halves side by side (xee_timing_t.sweep_streams), each launch
-        # then covers half the members -- read it off the grid (workgroups = tiles rounded up to a multiple of eight)
         wgs = fmeta[kname]["grid"] // fmeta[kname]["wg"]
-        ML = max(1, min(M, round(wgs / (ntx * nty))))
-        lower = planes * nr * nz * 4.0 * ML                                  # every plane byte once
-        upper = ntx * nty * ML * (planes * 64 * H + (1 if planes == 4 else 2) * 64) * 4.0  # every tile its whole footprint
+        planes = 4 if op == "BAROTROPIC" else 6
+        if short(kname) == "k_sweep_z":
+            # the streaming sweep: one wave per (strip of 52 own columns, pair of chunks, member); every wave reads 64 columns of
+            # its chunks' rows plus 2 T + 4 rows of run-in per chunk (and up to a fetch group more), four planes
+            T, W = 6, 52
+            strips = -(-(nr - 2) // W)
+            ML, P = M, 1
+            for ml in (M, max(1, M // 2)):
+                for pp in range(1, 65):
+                    if -(-(strips * pp * ml) // 8) * 8 == wgs:
+                        ML, P = ml, pp
+            Lc = -(-(nz - 2) // (2 * P))
+            lower = planes * nr * nz * 4.0 * ML
+            upper = strips * P * ML * 2 * (Lc + 2 * T + 4 + 8) * 64 * 4.0 * planes
+        else:
+            # physical bounds of the sweep's read bytes per launch (T = 8, 64 x H tiles stepping by 64 - 2T, H - 2T)
+            T, H = 8, (64 if op == "BAROTROPIC" else 48)
+            ntx, nty = -(-(nr - 1) // (64 - 2 * T)), -(-(nz - 1) // (H - 2 * T))
+            # members per LAUNCH: a large batch is solved as two halves side by side (xee_timing_t.sweep_streams), each launch
+            # then covers half the members -- read it off the grid (workgroups = tiles rounded up to a multiple of eight)
+            ML = max(1, min(M, round(wgs / (ntx * nty))))
+            lower = planes * nr * nz * 4.0 * ML                                  # every plane byte once
+            upper = ntx * nty * ML * (planes * 64 * H + (1 if planes == 4 else 2) * 64) * 4.0  # every tile its whole footprint
         read_bytes = max(min(2.0 * fetch * 1024.0, upper), lower)
         corr = fetch * 1024.0 / read_bytes
         rec = {"workload": wl, "kernel": kname, "short": short(kname), "nr": nr, "nz": nz, "members": ML, "members_in_batch": M, "operator": op,

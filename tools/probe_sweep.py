@@ -10,7 +10,7 @@ import bench, xee_pkg
 xee = xee_pkg.load()
 
 SHAPES = {"ensemble": (1024, 512, 32, 0, 480), "baroclinic": (1024, 512, 32, 1, 480), "single": (1024, 512, 1, 0, 3840),
-          "highres": (4096, 2048, 1, 0, 480)}
+          "highres": (4096, 2048, 1, 0, 480), "ens16": (1024, 512, 16, 0, 480), "ens8": (1024, 512, 8, 0, 480), "ens64": (1024, 512, 64, 0, 240)}
 CONFIGS = [{}, {"tb_T": 5}, {"tb_T": 7}, {"tb_T": 8}, {"tb_T": 10}, {"tile": 806}, {"tile": 806, "tb_T": 8}, {"kernel": 2}]
 ROUNDS = 3
 
@@ -37,7 +37,7 @@ def main():
             infos = {}
             for _ in range(ROUNDS):
                 for i, opts in enumerate(cfgs):
-                    for k in ("tb_T", "kernel", "tile"):
+                    for k in ("tb_T", "kernel", "tile", "z_pairs"):
                         e.set_option(k, {"tb_T": 8}.get(k, 0))
                     for k, v in opts.items():
                         e.set_option(k, v)

@@ -88,7 +88,7 @@ Defaults read_defaults()
 int set_option_in(SweepOpts& o, int& sync_checks, int& exact_serial, const char* key, int value)
 {
     struct Ent { const char* key; int* p; int lo, hi; };
-    const Ent tab[] = {{"tb_T", &o.T, 1, tb_max_T()}, {"kernel", &o.kernel, 0, 3}, {"q_exact_only", &o.q_exact_only, 0, 1},
+    const Ent tab[] = {{"tb_T", &o.T, 1, tb_max_T()}, {"kernel", &o.kernel, 0, 4}, {"z_pairs", &o.z_pairs, 0, 64}, {"q_exact_only", &o.q_exact_only, 0, 1},
                        {"elision", &o.elision, 0, 1}, {"tile", &o.tile, 0, 9999}, {"graph_blocks", &o.graph_blocks, 0, 8}, {"split_halves", &o.split_halves, 0, 1}, {"graph_events", &o.graph_events, 0, 1}, {"sync_checks", &sync_checks, 0, 1},
                        {"exact_sum_serial", &exact_serial, 0, 1}};
     if (!key) return fail(XEE_ERR_INVALID_ARGUMENT, "null option key");
@@ -145,6 +145,7 @@ struct xee_ensemble {
     hipStream_t cstream[2] = {nullptr, nullptr};
     hipEvent_t evE[3] = {nullptr, nullptr, nullptr}, evF[3] = {nullptr, nullptr, nullptr};   // sweep-side / check-side, by slot
     hipEvent_t evB[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};     // sweep block begin/end, by slot
+    hipEvent_t evZ[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};     // ... its run of k_sweep_z launches
     float* res2 = nullptr;       // residual planes of slots 1 and 2 (slot 0 is `res`); res3 only at depth 2
     float* res3 = nullptr;
     float* snap = nullptr;       // (depth + 1) x members planes: the iterate right after each check iteration, by slot
@@ -169,6 +170,10 @@ struct xee_ensemble {
     // streams, events, slots and norm workspaces are its own.
     bool is_view = false;
     xee_ensemble* half[2] = {nullptr, nullptr};
+    // k_sweep_z (xee_sweepz.hip): chunk pairs per strip while this solve's plain launches of sweep_z_T() iterations go to it
+    // (0: they do not); the members' extremes of |coe5| and |f| that decide it (device, 3 words per member)
+    int z_pairs_now = 0;
+    unsigned* zstat = nullptr;
     float* aos_stage = nullptr;        // Tier 1: device staging of the reference's AoS coe(9,nx,ny), kept with the ensemble
     int win_first = 0, win_count = 0;  // member window of the forcing_* / field_save / field_restore calls (0 = all members)
     MemberState* st_view = nullptr;    // 4 x members: the sweeps' VIEWS of the member states in the pipelined driver.  The
@@ -182,7 +187,9 @@ namespace {
 int alloc_planes(xee_ensemble* e, float** p, size_t nplanes = 1)
 {
     if (*p) return XEE_OK;
-    const size_t bytes = e->g.plane * e->g.members * nplanes * sizeof(float);
+    // (kPlaneSlack bytes more than the planes: the streaming sweep's 16-byte row fetches may run up to 12 bytes past the last
+    // plane's end -- xee_sweepz.hip)
+    const size_t bytes = e->g.plane * e->g.members * nplanes * sizeof(float) + kPlaneSlack;
     hipError_t err = hipMalloc(reinterpret_cast<void**>(p), bytes);
     if (err != hipSuccess) return fail(XEE_ERR_ALLOC, std::string("hipMalloc: ") + hipGetErrorString(err));
     HIPCHK(hipMemsetAsync(*p, 0, bytes, e->stream));
@@ -263,6 +270,68 @@ int detect_uniform_planes(xee_ensemble* e)
     return XEE_OK;
 }
 
+// Whether this solve's plain launches go to the streaming k_sweep_z, and with how many chunk pairs per strip
+// (e->z_pairs_now): the star operator from the generating planes, alpha = 1, a launch of `members` cases beside `streams` - 1
+// like it that fills the device (option "kernel" = 4: whatever it fills), and every member within the bounds under which the
+// kernel's hoisted division is the IEEE one (xee_sweepz.hip).  One pass over f, AP, CQ and a 12-byte-per-member copy.
+int z_decide(xee_ensemble* e, float alpha, int tb_T, int streams, int members)
+{
+    e->z_pairs_now = 0;
+    const int k = e->opts.kernel;
+    if (!(e->have_base && e->base_baro && alpha == 1.0f && (k == 0 || k == 4) && tb_T >= sweep_z_T())) return XEE_OK;
+    if (e->g.plane * sizeof(float) >= ((size_t)1 << 31) - 64) return XEE_OK;       // (byte offsets inside a plane are 32-bit)
+    int P = sweep_z_pairs(e->g, members, streams, k == 4 ? 0 : 70);
+    if (P > 0 && e->opts.z_pairs > 0) P = e->opts.z_pairs;
+    if (P <= 0) return XEE_OK;
+    if (!e->zstat) HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->zstat), 3 * sizeof(unsigned) * e->g.members));
+    launch_z_extremes(e->g, e->base, e->f, e->zstat, e->stream);
+    std::vector<unsigned> h(3 * (size_t)e->g.members);
+    HIPCHK(hipMemcpyAsync(h.data(), e->zstat, h.size() * sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (int m = 0; m < e->g.members; ++m)
+        if (!z_member_ok(&h[3 * (size_t)m])) return XEE_OK;
+    e->z_pairs_now = P;
+    return XEE_OK;
+}
+
+// The launches of `total` iterations up to a residual check (or the end): their lengths, first to last.  The last one writes
+// the residual when `to_check`.  A block that is not a whole number of launches starts with the short one: the residual-
+// writing launch at its end then is a full-length one (at 4 iterations it was HBM-bound by its three stores per point: 113 us
+// for 32 cases against 126 us for a plain 8-iteration launch; profiles/r02).
+// With k_sweep_z (zT > 0): its launches of zT, then k_sweep_q's residual-writing launch, which takes the remainder along --
+// every launch is a pass over all planes, ~75 us of memory traffic for 32 cases whatever its length (k_sweep_q: 82 us for
+// 2 iterations, 126 for 8), so 15 x 6 + 10 beats 2 + 15 x 6 + 8 (profiles/r03/final_kernel_stats.csv).  Without a check at
+// the end (the last block of a solve) the remainder goes first, never as a single iteration.
+void plan_block(int total, bool to_check, int tb_T, int zT, std::vector<int>* plan)
+{
+    plan->clear();
+    if (zT > 0 && tb_T > 1 && total >= (to_check ? tb_T : 0) + zT) {
+        if (to_check) {
+            int nz = (total - tb_T) / zT;
+            int wr = total - nz * zT;                     // tb_T .. tb_T + zT - 1
+            if (wr > tb_max_T()) { wr -= zT; nz += 1; }   // (tb_T above tb_max_T() - zT + 1: a shorter last launch instead, >= 2)
+            if (wr >= 2) {
+                for (int i = 0; i < nz; ++i) plan->push_back(zT);
+                plan->push_back(wr);
+                return;
+            }
+        } else {
+            int nz = total / zT, rem = total % zT;
+            if (rem == 1) { rem += zT; nz -= 1; }
+            if (rem) plan->push_back(rem);
+            for (int i = 0; i < nz; ++i) plan->push_back(zT);
+            return;
+        }
+    }
+    int left = total;
+    while (left > 0) {
+        const int rem = left % tb_T;
+        const int n = rem ? rem : tb_T;
+        plan->push_back(n);
+        left -= n;
+    }
+}
+
 // T iterations of the blocked sweep: from the four generating planes when assemble built them
 // (fewer bytes), else from the nine coefficient planes (any coefficients, e.g. a Tier-1 caller's)
 // returns true when the kernel itself also wrote the new iterate's interior into `snap` (k_sweep_q's residual-writing
@@ -272,6 +341,10 @@ bool launch_blocked(xee_ensemble* e, const float* psi_in, float* psi_out, float*
 {
     const int k = e->opts.kernel;
     if (!st) st = e->st;
+    if (e->z_pairs_now > 0 && !res && T == sweep_z_T() && alpha == 1.0f) {
+        launch_sweep_z(e->g, psi_in, psi_out, e->base, e->f, st, T, e->z_pairs_now, e->opts.q_exact_only, e->redo, &e->last_sweep, e->stream);
+        return false;
+    }
     if (e->have_base && k != 1) {
         if (k == 2) launch_sweep_tb4(e->g, psi_in, psi_out, e->base, e->f, res, st, alpha, T, e->base_baro, e->opts, &e->last_sweep, e->stream);
         else {
@@ -450,6 +523,7 @@ int xee_ensemble_destroy(xee_ensemble_t* e)
     for (auto& ev : e->evE) if (ev) hipEventDestroy(ev);
     for (auto& ev : e->evF) if (ev) hipEventDestroy(ev);
     for (auto& pr : e->evB) for (auto& ev : pr) if (ev) hipEventDestroy(ev);
+    for (auto& pr : e->evZ) for (auto& ev : pr) if (ev) hipEventDestroy(ev);
     if (e->res2) hipFree(e->res2);
     if (e->res3) hipFree(e->res3);
     if (e->ex_ws2) hipFree(e->ex_ws2);
@@ -459,6 +533,7 @@ int xee_ensemble_destroy(xee_ensemble_t* e)
     if (e->st_host2) hipHostFree(e->st_host2);
     if (e->st_view) hipFree(e->st_view);
     if (e->redo) hipFree(e->redo);
+    if (e->zstat) hipFree(e->zstat);
     for (auto& kv : e->stash) if (kv.second) hipFree(kv.second);
     if (e->aos_stage) hipFree(e->aos_stage);
     if (e->gres) hipFree(e->gres);
@@ -775,6 +850,7 @@ int solve_pipelined(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float 
         for (auto& ev : e->evE) HIPCHK(hipEventCreate(&ev));
         for (auto& ev : e->evF) HIPCHK(hipEventCreate(&ev));
         for (auto& pr : e->evB) for (auto& ev : pr) HIPCHK(hipEventCreate(&ev));
+        for (auto& pr : e->evZ) for (auto& ev : pr) HIPCHK(hipEventCreate(&ev));
         HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->st_host2), sizeof(MemberState) * 3 * g.members));
         HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->st_view), sizeof(MemberState) * NV * g.members));
     }
@@ -820,6 +896,7 @@ int solve_pipelined(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float 
     int final_check = -1;                         // index of a check that coincides with max_iter
     bool all_done = (max_iter == 0), block_open = false, sweeps_end_recorded = false;
 
+    int z_in_slot[3] = {0, 0, 0};                         // k_sweep_z launches between a slot's evZ pair
     // digest the results of the checks up to j, in order (check j's pipeline has finished when its slot's evF has)
     auto digest_upto = [&](int j) -> int {
         for (; digested <= j; ++digested) {
@@ -829,6 +906,11 @@ int solve_pipelined(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float 
                 float ms = 0.f;
                 HIPCHK(hipEventElapsedTime(&ms, e->evB[sl][0], e->evB[sl][1]));
                 e->timing.sweep_ms += ms;
+                if (z_in_slot[sl] > 0) {
+                    HIPCHK(hipEventElapsedTime(&ms, e->evZ[sl][0], e->evZ[sl][1]));
+                    e->timing.z_ms += ms;
+                    e->timing.z_timed_launches += z_in_slot[sl];
+                }
             }
             const MemberState* sh = e->st_host2 + (size_t)sl * g.members;
             all_done = true;
@@ -844,7 +926,7 @@ int solve_pipelined(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float 
     // Graphs.  A small batch is bound by how fast the host enqueues (one 1024x512 case: 13 launches of ~9 us per block
     // and eight more per check): a whole block -- the launches between two checks -- is captured once per distinct set
     // of arguments (ping-pong phase x slot x view: at most 2 x 3 x 4) and replayed as a graph.
-    struct BlockGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; bool snapped = false; int launches = 0; long long tiles = 0; };
+    struct BlockGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; bool snapped = false; int launches = 0, z_launches = 0; long long tiles = 0; };
     struct GraphCache {
         std::map<int, BlockGraph> m;
         ~GraphCache() { for (auto& kv : m) { if (kv.second.exec) hipGraphExecDestroy(kv.second.exec); if (kv.second.graph) hipGraphDestroy(kv.second.graph); } }
@@ -852,18 +934,21 @@ int solve_pipelined(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float 
     // (not on the legacy default stream, which cannot be captured; any capture failure falls back to plain launches)
     bool use_graphs = !large && tb_T > 1 && cs > tb_T && max_iter / cs >= 64 && s != nullptr;
     // the launches from iteration `from` up to `target` (a check iteration gets the residual plane and the snapshot)
+    std::vector<int> plan;
+    int z_enqueued = 0;                                   // k_sweep_z launches among those of the last enqueue_sweeps
     auto enqueue_sweeps = [&](int from, int target, bool to_check, int sl, int* cur_io, bool* snapped, int* launches, long long* tiles) {
-        int c2 = from;
-        *snapped = false; *launches = 0; *tiles = 0;
-        while (c2 < target) {
-            // a block that is not a whole number of launches starts with the short one: the residual-writing launch at its
-            // end then is a full-length one (at 4 iterations it was HBM-bound by its three stores per point: 113 us for
-            // 32 cases against 126 us for a plain 8-iteration launch; profiles/r02)
-            const int rem = (target - c2) % tb_T;
-            const int n = rem ? rem : tb_T;
-            c2 += n;
-            const bool check = to_check && c2 == target;
-            e->last_sweep.tiles = 0;
+        *snapped = false; *launches = 0; *tiles = 0; z_enqueued = 0;
+        plan_block(target - from, to_check, tb_T, e->z_pairs_now > 0 ? sweep_z_T() : 0, &plan);
+        // (large batches: the block's run of k_sweep_z launches between its own pair of events -- xee_timing_t.z_ms)
+        const bool time_z = block_events && to_check;
+        bool z_open = false;
+        for (size_t i = 0; i < plan.size(); ++i) {
+            const int n = plan[i];
+            const bool check = to_check && i + 1 == plan.size();
+            const bool will_stream = e->z_pairs_now > 0 && !check && n == sweep_z_T() && alpha == 1.0f;
+            if (time_z && will_stream && !z_open) { hipEventRecord(e->evZ[sl][0], s); z_open = true; }
+            if (z_open && !will_stream) { hipEventRecord(e->evZ[sl][1], s); z_open = false; }
+            e->last_sweep.tiles = 0; e->last_sweep.streamed = false;
             if (n == 1)
                 launch_sweep(g, e->psi[*cur_io], e->psi[*cur_io ^ 1], e->coe, e->f, check ? resbuf[sl] : nullptr, view, alpha, s);
             else if (launch_blocked(e, e->psi[*cur_io], e->psi[*cur_io ^ 1], check ? resbuf[sl] : nullptr, alpha, n, view,
@@ -872,7 +957,10 @@ int solve_pipelined(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float 
             *cur_io ^= 1;
             *launches += 1;
             *tiles += e->last_sweep.tiles;
+            if (e->last_sweep.streamed) z_enqueued += 1;
         }
+        if (z_open) hipEventRecord(e->evZ[sl][1], s);
+        if (time_z) z_in_slot[sl] = z_enqueued;
         if (to_check && !*snapped) launch_copy_active(g, e->psi[*cur_io], snapbuf[sl], view, s);   // the iterate this check belongs to
     };
 
@@ -896,6 +984,7 @@ int solve_pipelined(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float 
                 int c2 = cur;
                 if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess) {
                     enqueue_sweeps(cnt, target, true, sl, &c2, &bg.snapped, &bg.launches, &bg.tiles);
+                    bg.z_launches = z_enqueued;
                     if (hipStreamEndCapture(s, &bg.graph) != hipSuccess || hipGraphInstantiate(&bg.exec, bg.graph, nullptr, nullptr, 0) != hipSuccess)
                         bg.exec = nullptr;
                 }
@@ -905,11 +994,12 @@ int solve_pipelined(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float 
         if (use_graphs && check && cnt % cs == 0) {
             BlockGraph& bg = graphs.m[cur | (sl << 1) | (vi << 3)];
             HIPCHK(hipGraphLaunch(bg.exec, s));
-            snapped = bg.snapped; launches = bg.launches; tiles = bg.tiles;
+            snapped = bg.snapped; launches = bg.launches; tiles = bg.tiles; z_enqueued = bg.z_launches;
             cur ^= (launches & 1);
         } else {
             enqueue_sweeps(cnt, target, check, sl, &cur, &snapped, &launches, &tiles);
         }
+        e->timing.z_launches += z_enqueued;
         e->timing.sweep_launches += launches;
         e->timing.tiles += tiles;
         e->timing.iterations += target - cnt;
@@ -1090,7 +1180,7 @@ int solve_graphed(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float al
             const int n = rem ? rem : tb_T;             // the short launch first: the residual-writing one is full-length
             c2 += n;
             const bool check = c2 == target;
-            e->last_sweep.tiles = 0;
+            e->last_sweep.tiles = 0; e->last_sweep.streamed = false;
             if (n == 1)
                 launch_sweep(g, e->psi[*cur_io], e->psi[*cur_io ^ 1], e->coe, e->f, check ? e->gres + sl * mp : nullptr, view, alpha, s);
             else if (launch_blocked(e, e->psi[*cur_io], e->psi[*cur_io ^ 1], check ? e->gres + sl * mp : nullptr, alpha, n, view,
@@ -1178,7 +1268,7 @@ int solve_graphed(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float al
         int c2 = cnt;
         while (c2 < max_iter) {
             const int n = (max_iter - c2) < tb_T ? (max_iter - c2) : tb_T;
-            e->last_sweep.tiles = 0;
+            e->last_sweep.tiles = 0; e->last_sweep.streamed = false;
             if (n == 1) launch_sweep(g, e->psi[cur], e->psi[cur ^ 1], e->coe, e->f, nullptr, e->st, alpha, s);
             else launch_blocked(e, e->psi[cur], e->psi[cur ^ 1], nullptr, alpha, n, e->st, nullptr);
             cur ^= 1; c2 += n;
@@ -1258,6 +1348,7 @@ void aim_half_view(xee_ensemble* e, xee_ensemble* s, int m0)
     s->coe = e->coe + off; s->base = e->base ? e->base + off : nullptr;
     s->st = e->st + m0; s->st_host = e->st_host + m0; s->ex_slow = e->ex_slow + m0; s->redo = e->redo;
     s->cur = e->cur; s->opts = e->opts; s->have_base = e->have_base; s->base_baro = e->base_baro; s->uv = e->uv;
+    s->z_pairs_now = e->z_pairs_now;
     s->exact_serial = e->exact_serial; s->sync_checks = e->sync_checks;
 }
 
@@ -1300,14 +1391,17 @@ int xee_ensemble_solve(xee_ensemble_t* e, int max_iter, int check_step, int conv
         // a small batch with a long solve ahead: several check blocks per graph (solve_graphed); else one block at a time
         const bool small = (size_t)g.members * g.nx * g.ny < ((size_t)4 << 20);
         bool ran = false;
-        if (small && e->opts.graph_blocks && tb_T > 1 && cs > tb_T && max_iter / cs >= 64 && s != nullptr)
+        if (small && e->opts.graph_blocks && e->opts.kernel != 4 && tb_T > 1 && cs > tb_T && max_iter / cs >= 64 && s != nullptr)
             XCHK(solve_graphed(e, max_iter, cs, cp, alpha, tb_T, &ran));
         // a large batch that runs on k_sweep_q alone (no single-iteration launches): two halves of the member range, side by side
-        const bool q_only = e->have_base && (e->opts.kernel == 0 || e->opts.kernel == 3) && tb_T > 1 && cs % tb_T != 1 &&
+        const bool q_only = e->have_base && (e->opts.kernel == 0 || e->opts.kernel == 3 || e->opts.kernel == 4) && tb_T > 1 && cs % tb_T != 1 &&
                             (max_iter % cs) % tb_T != 1 && g.plane * sizeof(float) < ((size_t)1 << 31);
         // (measured on 1024x512 batches, tools/split_probe.py: +2 .. +4 % at 32 members, nothing at 64 and 256, a loss below 24 --
         // the halves must themselves still be large batches)
-        if (!ran && !small && q_only && e->opts.split_halves && g.members >= 32 && max_iter > 0 && s != nullptr && !e->is_view) {
+        const bool split = !ran && !small && q_only && e->opts.split_halves && g.members >= 32 && max_iter > 0 && s != nullptr && !e->is_view;
+        // plain launches by the streaming k_sweep_z where the batch fills the device with it and every member qualifies
+        if (!ran && max_iter > 0) XCHK(z_decide(e, alpha, tb_T, split ? 2 : 1, split ? (g.members + 1) / 2 : g.members));
+        if (split) {
             const int n0 = (g.members + 1) / 2, n1 = g.members - n0;
             XCHK(make_half_view(e, 0, 0, n0));
             XCHK(make_half_view(e, 1, n0, n1));
@@ -1339,6 +1433,8 @@ int xee_ensemble_solve(xee_ensemble_t* e, int max_iter, int check_step, int conv
             e->timing.solve_ms = std::max(e->timing.solve_ms, t1.solve_ms);
             e->timing.sweep_ms = std::max(e->timing.sweep_ms, t1.sweep_ms);   // the halves' sweeps run side by side
             e->timing.sweep_launches += t1.sweep_launches; e->timing.tiles += t1.tiles; e->timing.check_launches += t1.check_launches;
+            e->timing.z_launches += t1.z_launches; e->timing.z_timed_launches += t1.z_timed_launches;
+            e->timing.z_ms = std::max(e->timing.z_ms, t1.z_ms);
             e->timing.sweep_streams = 2;
             {
                 int n[2] = {0, 0};
@@ -1645,9 +1741,13 @@ int xee_ensemble_time_sweeps(xee_ensemble_t* e, int iters, int variant, float al
     launch_state_init(g, e->st, s);
     int64_t nl = 0;
     int cur = e->cur;
+    // (option "kernel" = 4: launches of sweep_z_T() iterations by k_sweep_z where the members qualify)
+    e->z_pairs_now = 0;
+    if (variant == 1 && e->opts.kernel == 4) XCHK(z_decide(e, alpha, e->opts.T, 1, g.members));
+    const int len = e->z_pairs_now > 0 ? sweep_z_T() : e->opts.T;
     HIPCHK(hipEventRecord(e->ev[0], s));
     for (int k = 0; k < iters;) {
-        const int n = variant == 0 ? 1 : ((iters - k) < e->opts.T ? (iters - k) : e->opts.T);
+        const int n = variant == 0 ? 1 : ((iters - k) < len ? (iters - k) : len);
         if (n == 1) launch_sweep(g, e->psi[cur], e->psi[cur ^ 1], e->coe, e->f, nullptr, e->st, alpha, s);
         else launch_blocked(e, e->psi[cur], e->psi[cur ^ 1], nullptr, alpha, n);
         cur ^= 1;

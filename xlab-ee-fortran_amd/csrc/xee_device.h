@@ -89,7 +89,9 @@ struct SweepOpts {
                            //         workloads once the prologue got cheaper, profiles/r02; round 1 used 6)
     int kernel = 0;        // "kernel": 0 auto | 1 nine coefficient planes (k_sweep_tb) | 2 generating planes, IEEE
                            //           division (k_sweep_tb4) | 3 generating planes, hoisted reciprocal (k_sweep_q)
-    int q_exact_only = 0;  // "q_exact_only": k_sweep_q runs its exact body on every tile
+                           //           | 4 as 3, with the streaming k_sweep_z wherever it applies, whatever the batch size
+    int z_pairs = 0;       // "z_pairs": chunk pairs per strip of k_sweep_z, 0 = chosen from the batch size
+    int q_exact_only = 0;  // "q_exact_only": k_sweep_q / k_sweep_z run their exact body on every tile / wave
     int elision = 1;       // "elision": k_sweep_tb skips coefficient planes that are uniform over the batch
     int tile = 0;          // "tile": NW*100 + R (waves x rows per lane), 0 = the kernel's default
     int graph_blocks = 8;  // "graph_blocks": check blocks per graph for small batches (solve_graphed), 1..8; 0: one block at a time
@@ -100,10 +102,13 @@ struct SweepOpts {
                            //                 121.8 against 126.7 ms per 100,000 iterations of one 1024x512 case (profiles/r03)
 };
 // what the last blocked launch was (xee_ensemble_sweep_info)
+constexpr size_t kPlaneSlack = 256;   // bytes allocated behind every array of planes (see alloc_planes)
+
 struct SweepDesc {
     const char* name = "none";
     int T = 0, tile_w = 0, tile_h = 0;
     long long tiles = 0;   // tiles (workgroups with work) of the last launch
+    bool streamed = false; // it was k_sweep_z
 };
 // coefficient planes that hold one bit pattern over the interior of every member (set by assemble)
 struct UniformVals {
@@ -135,6 +140,16 @@ bool launch_sweep_q(const Grid& g, const float* psi_in, float* psi_out, const fl
 void launch_quotient_check(unsigned long long seed, int blocks, int per_thread, int d_exp_lo, int d_exp_hi,
                            unsigned long long* mismatches /* device, 2 words */, float* first_bad /* device, 2 */,
                            hipStream_t s);
+// large batches, star operator, alpha = 1, plain launches: the blocked sweep streamed along z by single waves
+// (xee_sweepz.hip); bit-identical to launch_sweep_q where z_member_ok holds for every member
+int  sweep_z_T();                                         // iterations per launch (6)
+int  sweep_z_pairs(const Grid& g, int members, int streams, int min_eff_percent);   // chunk pairs per strip, 0 = "use k_sweep_q"
+void launch_z_extremes(const Grid& g, const float* base, const float* f, unsigned* zstat /* device, 3 per member */, hipStream_t s);
+bool z_member_ok(const unsigned* zstat3 /* host copy of one member's three words */);
+void launch_sweep_z(const Grid& g, const float* psi_in, float* psi_out, const float* base, const float* f,
+                    const MemberState* st, int T /* = sweep_z_T() */, int chunk_pairs, int exact_only,
+                    int* diag /* device, 2 ints or nullptr: [1] counts the waves that fell back to the exact body */,
+                    SweepDesc* desc, hipStream_t s);
 int  tb_max_T();
 // opt-in, non-parity: one 4-colour SOR iteration in place; residual plane of the current iterate
 void launch_sor_iteration(const Grid& g, float* psi, const float* coe, const float* f, const MemberState* st,
