@@ -16,6 +16,7 @@ for M in sizes:
         for name, arr in (("A", A), ("B", B), ("C", Cc), ("BC_INIT", bc), ("Q", Q)):
             e.upload(name, arr, first=m)
     res = {}
+    zinfo = {}
     for rnd in range(3):
         for split in (1, 0):
             e.set_option("split_halves", split)
@@ -24,6 +25,8 @@ for M in sizes:
             dt = time.perf_counter() - t0
             if rnd:
                 res.setdefault(split, []).append(dt)
+                t = e.timing()
+                zinfo[split] = (t["z_launches"], t["sweep_launches"], round(t["z_ms"] / max(t["z_timed_launches"] / t["sweep_streams"], 1) * 1e3, 1))
     print(f"M={M:4d}: split {min(res[1]) * 1e3:8.1f} ms ({M / min(res[1]) * iters / 1e5:6.2f} cases/s at 100k)   one stream {min(res[0]) * 1e3:8.1f} ms "
-          f"({M / min(res[0]) * iters / 1e5:6.2f})   streams {e.timing()['sweep_streams']}", flush=True)
+          f"({M / min(res[0]) * iters / 1e5:6.2f})   (k_sweep_z launches, all launches, us per k_sweep_z launch): split {zinfo[1]}  one {zinfo[0]}", flush=True)
     e.close()
