@@ -96,7 +96,7 @@ def main():
         planes = 4 if op == "BAROTROPIC" else 6
         if short(kname) == "k_sweep_z":
             # the streaming sweep: one wave per (strip of 52 own columns, pair of chunks, member); every wave reads 64 columns of
-            # its chunks' rows plus 2 T + 4 rows of run-in per chunk (and up to a fetch group more), four planes
+            # its chunks' rows plus 2 T rows of run-in per chunk (and up to two fetch groups more), four planes
             T, W = 6, 52
             strips = -(-(nr - 2) // W)
             ML, P = M, 1
@@ -106,7 +106,7 @@ def main():
                         ML, P = ml, pp
             Lc = -(-(nz - 2) // (2 * P))
             lower = planes * nr * nz * 4.0 * ML
-            upper = strips * P * ML * 2 * (Lc + 2 * T + 4 + 8) * 64 * 4.0 * planes
+            upper = strips * P * ML * 2 * (Lc + 2 * T + 6) * 64 * 4.0 * planes
         else:
             # physical bounds of the sweep's read bytes per launch (T = 8, 64 x H tiles stepping by 64 - 2T, H - 2T)
             T, H = 8, (64 if op == "BAROTROPIC" else 48)

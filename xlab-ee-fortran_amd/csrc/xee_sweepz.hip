@@ -93,8 +93,8 @@ __device__ __forceinline__ void z_for(F&& body) { z_for_impl(body, std::make_int
 }  // namespace
 
 // One wave: strip s (own columns s W + 1 .. s W + W, W = 64 - 2 T), member m, chunks c and c + P of 2 P: chunk c covers the
-// interior rows [1 + c Lc, 1 + (c + 1) Lc), clipped to ny - 2, and is walked from T + 2 rows before its first to T rows past
-// its last so that level T of its own rows is complete.
+// interior rows [1 + c Lc, 1 + (c + 1) Lc), clipped to ny - 2, and is walked from T rows before its first to T rows past its
+// last so that level T of its own rows is complete.
 // Fetch groups of TWO rows: one 16-byte LDS-DMA instruction per plane and group -- lanes 0..31 carry rows r, r + 1 of chunk a,
 // lanes 32..63 those of chunk b (16 lanes x 16 bytes = the 64 columns of a row) -- landing as [chunk][row][64] in LDS, two
 // groups ahead of the walk.  (Groups of four rows, one group ahead, 20 KB: the same speed.)
@@ -159,8 +159,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int sy0 = sch ? yb : ya, sy1 = sch ? yend_b : yend_a;
     const int o_w = ((lane - lo) & 63);
 
-    const int j_first = -T - 2;
-    const int n_ticks = Lc + 2 * T + 4;
+    // Level T of the chunk's rows 0 .. Lc - 1 needs level t of rows -(T - t) .. Lc - 1 + (T - t): the first row to take is -T (its
+    // CQ is row -T + 1's coe8), the last tick is the one of row Lc - 1 + T; whole groups of two rows (the second sends the results)
+    const int j_first = -T;
+    const int n_ticks = (Lc + 2 * T + 1) & ~1;
 
     auto walk = [&](auto exact_tag) -> bool {
         constexpr bool EXACT = decltype(exact_tag)::value;
@@ -189,6 +191,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             z_for<U>([&](auto uc) {
                 constexpr int u = decltype(uc)::value;
                 constexpr int sub = u & 1;
+                if (j0 + u >= n_ticks) return;            // (the last turn of the unrolled loop ends where the walk does)
                 const int jr = j_first + j0 + u;
                 const int rowa = ya + jr, rowb = yb + jr;
                 constexpr int slot = u % S, q = u & 1;
@@ -385,8 +388,8 @@ bool z_member_ok(const unsigned* zstat3)
 
 // Chunk pairs per strip for a launch over `members` cases that shares the device with `streams` - 1 launches like it.
 // The device holds 2048 waves of this kernel (eight per CU); a launch of n waves takes ceil(n / places) rounds, and a
-// chunk of Lc rows costs Lc + 2 T + 4 ticks: the P in 1 .. (ny - 2) / 64 with the largest product of the rounds' filling
-// and Lc / (Lc + 2 T + 4).  Returns 0 where that product is below `min_eff_percent`: k_sweep_q's tiles use the device better
+// chunk of Lc rows costs Lc + 2 T ticks: the P in 1 .. (ny - 2) / 64 with the largest product of the rounds' filling
+// and Lc / (Lc + 2 T).  Returns 0 where that product is below `min_eff_percent`: k_sweep_q's tiles use the device better
 // there (measured break-even near 70: 32 cases of 1024x512 reach 79 and gain 10 %, 16 cases reach 39 and lose 9 %).
 int sweep_z_T() { return 6; }
 
@@ -403,7 +406,7 @@ int sweep_z_pairs(const Grid& g, int members, int streams, int min_eff_percent)
         const long long n = strips * members * P;
         const long long rounds = (n + places - 1) / places;
         const int Lc = (g.ny - 2 + 2 * P - 1) / (2 * P);
-        const double eff = (double)n / (double)(rounds * places) * (double)Lc / (double)(Lc + 2 * T + 4);
+        const double eff = (double)n / (double)(rounds * places) * (double)Lc / (double)(Lc + 2 * T);
         if (eff > best_eff) { best_eff = eff; best = P; }
     }
     return best_eff * 100.0 >= (double)min_eff_percent ? best : 0;
