@@ -222,3 +222,32 @@ def test_a_large_batch_streams_by_itself_and_matches_the_reference_files():
             assert H.md5(outs[0][0][m]) == gold[key]["md5"]["rchi-[BAROTROPIC]-O.bin"], m
             hit += 1
     assert hit == 4, "reference anchors missing from golden_hashes.json"
+
+
+def test_random_shapes_chunkings_and_lengths():
+    """Forty random grids (8 .. 300 points a side, so every alignment of the last strip and of the chunks against the two-row
+    fetch groups and the eight-tick loop turn occurs), random chunk pairs, check steps and iteration counts; members that differ."""
+    rng = np.random.default_rng(20261005)
+    for trial in range(40):
+        nr, nz = int(rng.integers(8, 301)), int(rng.integers(8, 301))
+        M = int(rng.integers(1, 4))
+        cs = int(rng.integers(14, 60))
+        n = int(rng.integers(cs, 4 * cs))
+        pairs = int(rng.integers(0, 9))
+        outs = {}
+        for k in (3, 4):
+            with xee.Ensemble(nr, nz, M) as e:
+                e.set_option("kernel", k); e.set_option("z_pairs", pairs)
+                e.set_profiles(xee.profiles(nr, nz))
+                for m in range(M):
+                    A, B, Cc, bc = H.member_inputs(nr, nz, 10 * trial + m)
+                    f = _forcing(A, seed=trial + m)
+                    for name, arr in (("A", A), ("B", B), ("C", Cc), ("BC_INIT", bc), ("FORCING", f)):
+                        e.upload(name, arr, first=m)
+                e.assemble(0)
+                rec = e.solve(n, 1e-8, -1.0, 1.0, check_step=cs)
+                outs[k] = (e.download("PSI"), rec, e.timing())
+        tz = outs[4][2]
+        assert tz["z_launches"] > 0 and tz["inline_redo_tiles"] == 0, (trial, nr, nz, M, cs, n, pairs, tz)
+        assert biteq(outs[4][0], outs[3][0]), (trial, nr, nz, M, cs, n, pairs)
+        assert outs[4][1]["err_now"].tobytes() == outs[3][1]["err_now"].tobytes()
