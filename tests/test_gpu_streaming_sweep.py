@@ -251,3 +251,15 @@ def test_random_shapes_chunkings_and_lengths():
         assert tz["z_launches"] > 0 and tz["inline_redo_tiles"] == 0, (trial, nr, nz, M, cs, n, pairs, tz)
         assert biteq(outs[4][0], outs[3][0]), (trial, nr, nz, M, cs, n, pairs)
         assert outs[4][1]["err_now"].tobytes() == outs[3][1]["err_now"].tobytes()
+
+
+def test_streamed_launches_inside_block_graphs():
+    """A small batch with a long solve ahead replays its check blocks as HIP graphs (solve_pipelined); under "kernel" = 4 the
+    graphs hold k_sweep_z launches.  Same bits, same counts, as the tiled sweep."""
+    nr, nz, n = 130, 80, 7000
+    A, B, Cc, bc = H.member_inputs(nr, nz, 5)
+    f = _forcing(A)
+    want, rw, tw, _ = _run(A, B, Cc, bc, f, n, {"kernel": 3}, r1=1e-30)
+    got, rg, tg, _ = _run(A, B, Cc, bc, f, n, {"kernel": 4}, r1=1e-30)
+    assert tg["z_launches"] == 70 * 15 and tg["sweep_launches"] == 70 * 16 and tg["iterations"] == n
+    assert biteq(got, want) and rg["err_now"].tobytes() == rw["err_now"].tobytes() and rg["iters"].tolist() == rw["iters"].tolist()
