@@ -293,6 +293,7 @@ def main():
     streams = 1
     z_launches = z_timed = 0
     z_ms = 0.0
+    shared_planes = 0
     for _ in range(args.steps):
         rec = step()
         t = ens.timing()
@@ -301,6 +302,7 @@ def main():
         launches += t["sweep_launches"]
         streams = max(1, t["sweep_streams"])
         z_launches += t["z_launches"]; z_timed += t["z_timed_launches"]; z_ms += t["z_ms"]
+        shared_planes = int(t["shared_planes"])
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -341,8 +343,12 @@ def main():
         if not traffic_source["matches_build"]:
             ent = None
         traffic = ent["bytes_per_launch"] if ent else None
-        b_alg = BYTES_RECOMPUTE[operator]
-        hbm = {"algorithmic_bytes_per_point_iter": b_alg,
+        # Members that share their operator (this synthetic ensemble: A = C = 1 for every member) read ONE copy of
+        # each generating plane they share (xee_timing_t.shared_planes): that plane's 4 B per point count once per launch, not
+        # once per member
+        n_shared = bin(shared_planes & (3 if operator == "BAROTROPIC" else 15)).count("1")
+        b_alg = BYTES_RECOMPUTE[operator] - 4.0 * n_shared + 4.0 * n_shared / members_per_launch
+        hbm = {"algorithmic_bytes_per_point_iter": b_alg, "generating_planes_shared_by_all_members": n_shared,
                "compulsory_bytes_per_launch": b_alg * interior * members_per_launch,   # one blocked pass touches every plane once
                # (all concurrent launches together: `streams` of them run side by side)
                "compulsory_GBps": b_alg * interior * M / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0,
@@ -364,7 +370,7 @@ def main():
         common = {"kernel": kernel_label, "avg_launch_us": avg_launch_s * 1e6, "launches": launches, "concurrent_launches": streams,
                   "members_per_launch": members_per_launch, "point_iterations_per_launch": point_iters / max(launches, 1),
                   "traffic_source": traffic_source, "hbm": hbm}
-        if streamed:
+        if streamed and n_shared == 0:
             # algorithmic bytes of one launch (20 B per point and pass x its points) over its measured
             # duration, all concurrent launches together.  Cross-check: every sweep launch of the timed region is one pass
             # over the planes, so their bytes over the sweeps' device time is a second, coarser figure (it includes the longer
@@ -379,8 +385,13 @@ def main():
                     "why_hbm": "with the arithmetic taken out the walk takes 85 % of its time (4.9 TB/s); profiles/r03/z_ablation.txt",
                     "z_launches": z_launches, "z_timed_launches": z_timed, "valu": valu, **common}
         else:
+            # k_sweep_q everywhere; and k_sweep_z once the members share AP and CQ: 12.5 instead of 20 B per point and pass leave
+            # it short of the HBM bound (2.9 TB/s of real traffic) and nearest the VALU's (profiles/r03/z_ablation.txt: 10.1 us per
+            # iteration with its memory operations removed, 12.3 with them)
             roof = {"bound": "valu", **{k: valu[k] for k in ("achieved", "peak", "unit", "frac")}, "traffic": traffic,
                     **{k: v for k, v in valu.items() if k not in ("achieved", "peak", "unit", "frac")}, **common}
+            if streamed:
+                roof.update({"z_launches": z_launches, "z_timed_launches": z_timed})
         out = {
             "metric": "diagnosed cases/s (1024x512 r-z grid, damped Jacobi to max_iter, bit-identical to the reference)",
             "value": cases / dt, "unit": "cases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

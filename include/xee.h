@@ -66,6 +66,8 @@ int         xee_device_count(int *count);  /* number of visible HIP devices (0 i
  *                      max(2^-100, max |coe5| 2^-120) -- tested per solve (one pass over three planes); the residual-writing
  *                      launch of every check block stays k_sweep_q's
  *   "z_pairs"          chunks of rows per strip of k_sweep_z, in pairs: 1..64, 0 = chosen from the batch (0)
+ *   "share_planes"     0: every member reads its own copy of the operator's generating planes even where all members hold the
+ *                      same ones (1: such planes are read from one copy -- tested once per assembled operator)
  *   "q_exact_only"     1: k_sweep_q / k_sweep_z run their exact (fallback) body on every tile / wave
  *   "elision"          0: k_sweep_tb loads coefficient planes even when they are uniform over the batch (1)
  *   "tile"             NW*100+R: waves x rows per lane of a blocked tile, 0 = the kernel's default
@@ -293,6 +295,9 @@ typedef struct {
     double  z_ms;              /* device time between the first and the last k_sweep_z launch of every check block (HIP events on the
                                   launches' stream; large batches only; two halves: the longer of the two) and the number of launches */
     int64_t z_timed_launches;  /* between those events: one k_sweep_z launch lasts z_ms / (z_timed_launches / sweep_streams) */
+    int64_t shared_planes;     /* bit k: generating plane k of the operator (0 AP, 1 CQ, 2 BX, 3 BY) held the same bits for every
+                                  member in the last solve, and k_sweep_q / k_sweep_z read ONE copy of it for all of them (members
+                                  that share their operator: an ensemble that varies the forcing only; option "share_planes") */
 } xee_timing_t;
 
 /* flags of xee_ensemble_solve */

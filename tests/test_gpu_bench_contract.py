@@ -33,7 +33,10 @@ def test_bench_prints_one_json_line_with_required_keys():
     ts = r["traffic_source"]              # (no PMC entry exists for this toy size: nothing may be quoted)
     assert ts["entry_found"] is False and ts["matches_build"] is False and r["traffic"] is None and len(ts["this_build_hash"]) == 64
     h = r["hbm"]
-    assert h["peak_GBps"] == 8000.0 and h["algorithmic_bytes_per_point_iter"] == 20.0 and h["compulsory_GBps"] > 0
+    # (the bench's members share their operator -- A = C = 1 -- so AP and CQ count once per launch of 2 members, not per member:
+    # 4 B psi + 4 B f in, 4 B psi out, and 2 x 4 B / 2)
+    assert h["generating_planes_shared_by_all_members"] == 2 and h["algorithmic_bytes_per_point_iter"] == 12.0 + 8.0 / 2
+    assert h["peak_GBps"] == 8000.0 and h["compulsory_GBps"] > 0
     assert h["real_frac_of_peak"] is None or 0 < h["real_frac_of_peak"] <= 1.0
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["value"] > 0 and "sample" in c

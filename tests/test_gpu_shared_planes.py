@@ -1,0 +1,125 @@
+"""Members that share their operator read ONE copy of its generating planes (Grid.base_shared, option "share_planes"):
+the test that finds them (bit for bit, plane by plane), the sweeps' results with and without it, for k_sweep_q and
+k_sweep_z, both operators, and what an upload or a new assemble does to the decision."""
+import numpy as np
+import pytest
+
+import orchelp as H
+import xee_pkg
+
+pytestmark = pytest.mark.gpu
+
+xee = xee_pkg.load()
+
+AP, CQ, BX, BY = 1, 2, 4, 8
+
+
+def biteq(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def _members(nr, nz, M, vary):
+    """M members from one rich field set; `vary` names the inputs that differ between members."""
+    A0, B0, C0, bc0 = H.rich_inputs(nr, nz, seed=11)
+    rng = np.random.default_rng(5)
+    out = []
+    for m in range(M):
+        A, B, Cc, bc = A0.copy(), B0.copy(), C0.copy(), bc0.copy()
+        if "A" in vary and m == M - 1:
+            A[nz // 2, nr // 3] *= np.float32(1.0 + 2.0 ** -20)           # one value, one member, one ulp-ish
+        if "C" in vary and m == 1 % M:
+            Cc[nz // 4, nr // 2] *= np.float32(1.0 + 2.0 ** -20)
+        if "B" in vary:
+            B = (B + np.float32(1e-3 * (m + 1)) * rng.standard_normal(B.shape)).astype(np.float32)
+        bc = (bc * np.float32(1.0 + 0.1 * m)).astype(np.float32)
+        out.append((A, B, Cc, bc))
+    return out
+
+
+def _solve(members, variant, n, options, forcing="B"):
+    nz, nr = members[0][0].shape
+    M = len(members)
+    with xee.Ensemble(nr, nz, M) as e:
+        for k, v in options.items():
+            e.set_option(k, v)
+        e.set_profiles(xee.profiles(nr, nz))
+        for m, (A, B, Cc, bc) in enumerate(members):
+            for name, arr in (("A", A), ("B", B), ("C", Cc), ("BC_INIT", bc)):
+                e.upload(name, arr, first=m)
+            if forcing != "B":
+                e.upload("FORCING", (-B * np.float32(1.0 + 0.01 * m)).astype(np.float32), first=m)
+        if forcing == "B":
+            e.forcing_from_B()
+        e.assemble(variant)
+        rec = e.solve(n, 1e-8, -1.0, 1.0)
+        return e.download("PSI"), rec, e.timing()
+
+
+@pytest.mark.parametrize("variant,vary,want", [
+    (0, "B", AP | CQ),                      # BAROTROPIC: B is not in the operator
+    (1, "", AP | CQ | BX | BY),             # BAROCLINIC, the same A, B, C for all members (only the first guess differs)
+    (1, "B", AP | CQ),                      # ... B differs: BX, BY do
+    (0, "AB", CQ),                          # one value of one member's A differs: AP is not shared
+    (0, "CB", AP),
+    (1, "AC", BX | BY),
+])
+def test_which_planes_are_shared(variant, vary, want):
+    nr, nz, M, n = 150, 90, 5, 120
+    mem = _members(nr, nz, M, vary)
+    psi, rec, t = _solve(mem, variant, n, {})
+    assert t["shared_planes"] == want, (variant, vary, t["shared_planes"])
+    for opts in ({"share_planes": 0}, {"kernel": 4}, {"kernel": 4, "share_planes": 0}):
+        p2, r2, t2 = _solve(mem, variant, n, opts)
+        assert t2["shared_planes"] == (0 if opts.get("share_planes") == 0 else want)
+        assert biteq(p2, psi) and r2["err_now"].tobytes() == rec["err_now"].tobytes(), (variant, vary, opts)
+    # each member against the same member alone (one member: all planes trivially "shared")
+    for m in (0, M - 1):
+        solo, rs, ts = _solve([mem[m]], variant, n, {})
+        assert biteq(solo[0], psi[m]) and ts["shared_planes"] == (AP | CQ if variant == 0 else AP | CQ | BX | BY)
+
+
+def test_decision_follows_the_planes():
+    """The test runs once per assembled operator: a new assemble after an upload that makes one member differ takes it back;
+    changing the option between solves does too."""
+    nr, nz, M, n = 130, 70, 4, 60
+    mem = _members(nr, nz, M, "B")
+    with xee.Ensemble(nr, nz, M) as e:
+        e.set_profiles(xee.profiles(nr, nz))
+        for m, (A, B, Cc, bc) in enumerate(mem):
+            for name, arr in (("A", A), ("B", B), ("C", Cc), ("BC_INIT", bc)):
+                e.upload(name, arr, first=m)
+        e.forcing_from_B(); e.assemble(0)
+        e.solve(n, 1e-8, -1.0, 1.0)
+        first = e.download("PSI")
+        assert e.timing()["shared_planes"] == (AP | CQ)
+        e.set_option("share_planes", 0)
+        e.solve(n, 1e-8, -1.0, 1.0)
+        assert e.timing()["shared_planes"] == 0 and biteq(e.download("PSI"), first)
+        e.set_option("share_planes", 1)
+        A2 = mem[2][0].copy(); A2[10, 10] = np.float32(3.0)
+        e.upload("A", A2, first=2)
+        e.assemble(0)
+        e.solve(n, 1e-8, -1.0, 1.0)
+        assert e.timing()["shared_planes"] == CQ
+        changed = e.download("PSI")
+        assert biteq(changed[0], first[0]) and not biteq(changed[2], first[2])
+    mem2 = [list(x) for x in mem]; mem2[2][0] = A2
+    ref, _, _ = _solve([tuple(x) for x in mem2], 0, n, {"share_planes": 0})
+    assert biteq(changed, ref)
+
+
+def test_streamed_large_batch_with_a_shared_operator_against_the_reference_files():
+    """The bench's batch (32 x 1024x512, A = C = 1 for every member) shares AP and CQ; members 1, 2, 3, 7 against the md5 of the
+    reference program's own output (200 iterations), everything against the unshared run."""
+    import json
+    from pathlib import Path
+    gold = json.loads((Path(__file__).parent / "golden" / "golden_hashes.json").read_text())
+    nr, nz, M, n = 1024, 512, 32, 200
+    mem = [H.member_inputs(nr, nz, m) for m in range(M)]
+    psi, rec, t = _solve(mem, 0, n, {})
+    assert t["shared_planes"] == (AP | CQ) and t["z_launches"] > 0
+    p0, r0, t0 = _solve(mem, 0, n, {"share_planes": 0})
+    assert t0["shared_planes"] == 0 and biteq(psi, p0) and rec["err_now"].tobytes() == r0["err_now"].tobytes()
+    for m in (1, 2, 3, 7):
+        assert H.md5(psi[m]) == gold[f"member{m}_1024x512_200"]["md5"]["rchi-[BAROTROPIC]-O.bin"], m

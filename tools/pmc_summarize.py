@@ -94,6 +94,14 @@ def main():
         fetch = mean(fv[kname]["FETCH_SIZE"])
         wgs = fmeta[kname]["grid"] // fmeta[kname]["wg"]
         planes = 4 if op == "BAROTROPIC" else 6
+        # generating planes that all members share are read from ONE copy (xee_timing_t.shared_planes, printed by the workload)
+        shared = 0
+        try:
+            import re as _re
+            m_ = _re.search(r"shared_planes=(\d+)", (base / "fetch.log").read_text())
+            shared = bin(int(m_.group(1)) & (3 if op == "BAROTROPIC" else 15)).count("1") if m_ else 0
+        except OSError:
+            pass
         if short(kname) == "k_sweep_z":
             # the streaming sweep: one wave per (strip of 52 own columns, pair of chunks, member); every wave reads 64 columns of
             # its chunks' rows plus 2 T rows of run-in per chunk (and up to two fetch groups more), four planes
@@ -105,7 +113,7 @@ def main():
                     if -(-(strips * pp * ml) // 8) * 8 == wgs:
                         ML, P = ml, pp
             Lc = -(-(nz - 2) // (2 * P))
-            lower = planes * nr * nz * 4.0 * ML
+            lower = (planes - shared) * nr * nz * 4.0 * ML + shared * nr * nz * 4.0
             upper = strips * P * ML * 2 * (Lc + 2 * T + 6) * 64 * 4.0 * planes
         else:
             # physical bounds of the sweep's read bytes per launch (T = 8, 64 x H tiles stepping by 64 - 2T, H - 2T)
@@ -114,11 +122,12 @@ def main():
             # members per LAUNCH: a large batch is solved as two halves side by side (xee_timing_t.sweep_streams), each launch
             # then covers half the members -- read it off the grid (workgroups = tiles rounded up to a multiple of eight)
             ML = max(1, min(M, round(wgs / (ntx * nty))))
-            lower = planes * nr * nz * 4.0 * ML                                  # every plane byte once
+            lower = (planes - shared) * nr * nz * 4.0 * ML + shared * nr * nz * 4.0   # every plane byte once (a shared plane: one copy)
             upper = ntx * nty * ML * (planes * 64 * H + (1 if planes == 4 else 2) * 64) * 4.0  # every tile its whole footprint
         read_bytes = max(min(2.0 * fetch * 1024.0, upper), lower)
         corr = fetch * 1024.0 / read_bytes
         rec = {"workload": wl, "kernel": kname, "short": short(kname), "nr": nr, "nz": nz, "members": ML, "members_in_batch": M, "operator": op,
+               "generating_planes_shared": shared,
                "dispatches": len(fv[kname]["FETCH_SIZE"]), **fmeta[kname],
                "FETCH_SIZE_kib": fetch, "fetch_calibration": cal, "fetch_correction": corr, "load_width_B": width,
                "read_bytes": read_bytes, "read_bytes_bounds": {"tally": fetch * 1024.0, "twice_tally": 2048.0 * fetch,

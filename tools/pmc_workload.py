@@ -37,6 +37,7 @@ def main():
         e.forcing_from_B()                 # k_negate: float4 copy of M planes (known bytes, 16 B/lane)
         e.assemble(variant)
         e.solve(iters, 1e-8, -1.0, 1.0)
+        print("shared_planes=%d" % e.timing()["shared_planes"], flush=True)   # (read by tools/pmc_summarize.py from the pass's log)
         e.cal_eta()                        # k_cal_eta: dword reads of M planes (known bytes, 4 B/lane)
         e.ee_scalars()
 

@@ -37,8 +37,8 @@ def main():
             infos = {}
             for _ in range(ROUNDS):
                 for i, opts in enumerate(cfgs):
-                    for k in ("tb_T", "kernel", "tile", "z_pairs"):
-                        e.set_option(k, {"tb_T": 8}.get(k, 0))
+                    for k in ("tb_T", "kernel", "tile", "z_pairs", "share_planes"):
+                        e.set_option(k, {"tb_T": 8, "share_planes": 1}.get(k, 0))
                     for k, v in opts.items():
                         e.set_option(k, v)
                     ms, n = e.time_sweeps(iters, 1)

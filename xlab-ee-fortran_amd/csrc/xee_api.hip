@@ -88,7 +88,7 @@ Defaults read_defaults()
 int set_option_in(SweepOpts& o, int& sync_checks, int& exact_serial, const char* key, int value)
 {
     struct Ent { const char* key; int* p; int lo, hi; };
-    const Ent tab[] = {{"tb_T", &o.T, 1, tb_max_T()}, {"kernel", &o.kernel, 0, 4}, {"z_pairs", &o.z_pairs, 0, 64}, {"q_exact_only", &o.q_exact_only, 0, 1},
+    const Ent tab[] = {{"tb_T", &o.T, 1, tb_max_T()}, {"kernel", &o.kernel, 0, 4}, {"z_pairs", &o.z_pairs, 0, 64}, {"share_planes", &o.share_planes, 0, 1}, {"q_exact_only", &o.q_exact_only, 0, 1},
                        {"elision", &o.elision, 0, 1}, {"tile", &o.tile, 0, 9999}, {"graph_blocks", &o.graph_blocks, 0, 8}, {"split_halves", &o.split_halves, 0, 1}, {"graph_events", &o.graph_events, 0, 1}, {"sync_checks", &sync_checks, 0, 1},
                        {"exact_sum_serial", &exact_serial, 0, 1}};
     if (!key) return fail(XEE_ERR_INVALID_ARGUMENT, "null option key");
@@ -174,6 +174,8 @@ struct xee_ensemble {
     // (0: they do not); the members' extremes of |coe5| and |f| that decide it (device, 3 words per member)
     int z_pairs_now = 0;
     unsigned* zstat = nullptr;
+    bool base_shared_known = false;    // Grid.base_shared describes the current generating planes (else: tested at the next solve)
+    unsigned* shared_differs = nullptr; // device word of the test
     float* aos_stage = nullptr;        // Tier 1: device staging of the reference's AoS coe(9,nx,ny), kept with the ensemble
     int win_first = 0, win_count = 0;  // member window of the forcing_* / field_save / field_restore calls (0 = all members)
     MemberState* st_view = nullptr;    // 4 x members: the sweeps' VIEWS of the member states in the pipelined driver.  The
@@ -267,6 +269,27 @@ int detect_uniform_planes(xee_ensemble* e)
     HIPCHK(hipStreamSynchronize(e->stream));
     e->uv.mask = (~differs) & 0x1ffu;
     for (int k = 0; k < 9; ++k) e->uv.v[k] = v[k];
+    return XEE_OK;
+}
+
+// Which generating planes do all members share?  (Grid.base_shared; tested once per set of planes: one pass over them and a
+// 4-byte copy.)  Members that share their operator -- an ensemble that varies the forcing only, the kinds of a source-term
+// sweep -- then read ONE copy of AP, CQ (, BX, BY), which stays in the caches: 12 instead of 20 bytes per point and pass from HBM.
+int base_shared_update(xee_ensemble* e)
+{
+    if (!e->have_base || e->base_shared_known) return XEE_OK;
+    e->g.base_shared = 0;
+    e->base_shared_known = true;
+    if (!e->opts.share_planes) return XEE_OK;
+    const int nplanes = e->base_baro ? 2 : 4;
+    const unsigned all = (1u << nplanes) - 1u;
+    if (e->g.members < 2) { e->g.base_shared = (int)all; return XEE_OK; }
+    if (!e->shared_differs) HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->shared_differs), sizeof(unsigned)));
+    launch_base_shared_check(e->g, e->base, nplanes, e->shared_differs, e->stream);
+    unsigned differs = all;
+    HIPCHK(hipMemcpyAsync(&differs, e->shared_differs, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->g.base_shared = (int)(~differs & all);
     return XEE_OK;
 }
 
@@ -536,6 +559,7 @@ int xee_ensemble_destroy(xee_ensemble_t* e)
     if (e->st_view) hipFree(e->st_view);
     if (e->redo) hipFree(e->redo);
     if (e->zstat) hipFree(e->zstat);
+    if (e->shared_differs) hipFree(e->shared_differs);
     for (auto& kv : e->stash) if (kv.second) hipFree(kv.second);
     if (e->aos_stage) hipFree(e->aos_stage);
     if (e->gres) hipFree(e->gres);
@@ -599,6 +623,7 @@ int xee_ensemble_set_option(xee_ensemble_t* e, const char* key, int value)
     if (!e) return fail(XEE_ERR_INVALID_ARGUMENT, "null ensemble");
     int sc = e->sync_checks ? 1 : 0, xs = e->exact_serial ? 1 : 0;
     XCHK(set_option_in(e->opts, sc, xs, key, value));
+    e->base_shared_known = false;                       // ("share_planes" may have changed)
     e->sync_checks = sc != 0;
     e->exact_serial = xs != 0;
     return XEE_OK;
@@ -786,6 +811,7 @@ int xee_ensemble_assemble(xee_ensemble_t* e, int variant)
     launch_base_planes(e->g, e->sA, variant == XEE_BAROCLINIC ? e->sB : nullptr, e->sC, e->base, e->dr, e->dz, e->stream);
     XCHK(check_launch("base planes"));
     e->have_base = true;
+    e->base_shared_known = false; e->g.base_shared = 0;
     e->base_baro = (variant == XEE_BAROTROPIC);
     return XEE_OK;
 }
@@ -801,6 +827,7 @@ int xee_ensemble_assemble_solver(xee_ensemble_t* e, int use_b)
     launch_base_planes(e->g, e->sA, use_b ? e->sB : nullptr, e->sC, e->base, e->dr, e->dz, e->stream);
     XCHK(check_launch("base planes"));
     e->have_base = true;
+    e->base_shared_known = false; e->g.base_shared = 0;
     e->base_baro = !use_b;
     return XEE_OK;
 }
@@ -1350,7 +1377,7 @@ void aim_half_view(xee_ensemble* e, xee_ensemble* s, int m0)
     s->coe = e->coe + off; s->base = e->base ? e->base + off : nullptr;
     s->st = e->st + m0; s->st_host = e->st_host + m0; s->ex_slow = e->ex_slow + m0; s->redo = e->redo;
     s->cur = e->cur; s->opts = e->opts; s->have_base = e->have_base; s->base_baro = e->base_baro; s->uv = e->uv;
-    s->z_pairs_now = e->z_pairs_now;
+    s->z_pairs_now = e->z_pairs_now; s->g.base_shared = e->g.base_shared;
     s->exact_serial = e->exact_serial; s->sync_checks = e->sync_checks;
 }
 
@@ -1377,6 +1404,7 @@ int xee_ensemble_solve(xee_ensemble_t* e, int max_iter, int check_step, int conv
     cp.debug = (flags & XEE_SOLVE_TRACE) ? 2 : 0;
     const Grid& g = e->g;
     hipStream_t s = e->stream;
+    XCHK(base_shared_update(e));                        // (which generating planes all members share: Grid.base_shared)
 
     // :171-174  workspace = dat; the first iteration reads dat.  Both ping-pong planes carry the rim.
     if (flags & XEE_SOLVE_KEEP_PSI) launch_copy2(g, e->psi[e->cur], e->psi[e->cur ^ 1], nullptr, s);
@@ -1700,6 +1728,7 @@ int xee_ensemble_timing(xee_ensemble_t* e, xee_timing_t* out)
 {
     if (!e || !out) return fail(XEE_ERR_INVALID_ARGUMENT, "null argument");
     *out = e->timing;
+    out->shared_planes = e->base_shared_known ? e->g.base_shared : 0;
     return XEE_OK;
 }
 
@@ -1745,6 +1774,7 @@ int xee_ensemble_time_sweeps(xee_ensemble_t* e, int iters, int variant, float al
     int cur = e->cur;
     // (option "kernel" = 4: launches of sweep_z_T() iterations by k_sweep_z where the members qualify)
     e->z_pairs_now = 0;
+    XCHK(base_shared_update(e));
     if (variant == 1 && e->opts.kernel == 4) XCHK(z_decide(e, alpha, e->opts.T, 1, g.members));
     const int len = e->z_pairs_now > 0 ? sweep_z_T() : e->opts.T;
     HIPCHK(hipEventRecord(e->ev[0], s));
@@ -1945,6 +1975,7 @@ int cache_try(xee_ensemble* e)
     launch_base_planes(e->g, cc.abc, cc.b_zero ? nullptr : cc.abc + e->g.plane, cc.abc + 2 * e->g.plane, e->base, cc.dx, cc.dy, e->stream);
     XCHK(check_launch("base planes (Tier 1)"));
     e->have_base = true;
+    e->base_shared_known = false; e->g.base_shared = 0;
     e->base_baro = cc.b_zero;
     return XEE_OK;
 }

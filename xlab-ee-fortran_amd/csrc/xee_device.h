@@ -22,6 +22,9 @@ struct Grid {
     size_t plane;    // floats per member per field = pitch * ny
     size_t kstride;  // floats between planes k and k + 1 of the SoA fields (coe, base); 0 = members * plane.  Non-zero in the
                      // view of a member sub-range that xee_ensemble_solve hands to one of its two sweep streams (k_sweep_q only)
+    int base_shared; // bit k: generating plane k (AP, CQ, BX, BY) holds the same bits for every member -- members that share
+                     // their operator, e.g. an ensemble that varies the forcing only -- so k_sweep_q / k_sweep_z read member 0's
+                     // copy for all of them (4 MB that stay in the caches instead of 8 B per point and pass from HBM)
 };
 
 // per-member solver state, owned by the device between checks
@@ -91,6 +94,7 @@ struct SweepOpts {
                            //           division (k_sweep_tb4) | 3 generating planes, hoisted reciprocal (k_sweep_q)
                            //           | 4 as 3, with the streaming k_sweep_z wherever it applies, whatever the batch size
     int z_pairs = 0;       // "z_pairs": chunk pairs per strip of k_sweep_z, 0 = chosen from the batch size
+    int share_planes = 1;  // "share_planes": generating planes that are the same for all members are read from member 0's copy
     int q_exact_only = 0;  // "q_exact_only": k_sweep_q / k_sweep_z run their exact body on every tile / wave
     int elision = 1;       // "elision": k_sweep_tb skips coefficient planes that are uniform over the batch
     int tile = 0;          // "tile": NW*100 + R (waves x rows per lane), 0 = the kernel's default
@@ -117,6 +121,7 @@ struct UniformVals {
 };
 void launch_uniform_check(const Grid& g, const float* coe, unsigned* differs /* device, 1 word */, hipStream_t s);
 void launch_coe_compare(const Grid& g, const float* x, const float* y, unsigned* differs /* device, 1 word */, hipStream_t s);
+void launch_base_shared_check(const Grid& g, const float* base, int nplanes, unsigned* differs /* device, 1 word: bit k = plane k differs between members */, hipStream_t s);
 // T damped-Jacobi iterations in one launch (temporally blocked kernel), 2 <= T <= tb_max_T()
 void launch_sweep_tb(const Grid& g, const float* psi_in, float* psi_out, const float* coe,
                      const float* f, float* res /* residual of the LAST iteration, or nullptr */,

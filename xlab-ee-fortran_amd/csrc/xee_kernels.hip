@@ -932,6 +932,29 @@ __global__ __launch_bounds__(256) void k_coe_compare(Grid g, const float* __rest
     if (bad) atomicOr(differs, 1u);
 }
 
+// Do all members hold the same generating planes?  Bit k of *differs: plane k of some member differs from member 0's in
+// some word (the whole plane, pads included: the sweeps read rim rows and clamped columns too).
+__global__ __launch_bounds__(256) void k_base_shared_check(Grid g, const float* __restrict__ base, unsigned* __restrict__ differs)
+{
+    const size_t ks = g.kstride ? g.kstride : (size_t)g.members * g.plane;
+    const int k = blockIdx.z, m = blockIdx.y + 1;
+    const unsigned* __restrict__ p0 = reinterpret_cast<const unsigned*>(base + (size_t)k * ks);
+    const unsigned* __restrict__ pm = p0 + (size_t)m * g.plane;
+    bool d = false;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < g.plane; i += (size_t)gridDim.x * 256) d = d || p0[i] != pm[i];
+    if (__builtin_amdgcn_ballot_w64(d) != 0 && (threadIdx.x & 63) == 0) {
+        const unsigned cur = __hip_atomic_load(differs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!((cur >> k) & 1u)) atomicOr(differs, 1u << k);
+    }
+}
+
+void launch_base_shared_check(const Grid& g, const float* base, int nplanes, unsigned* differs, hipStream_t s)
+{
+    (void)hipMemsetAsync(differs, 0, sizeof(unsigned), s);
+    if (g.members < 2) return;
+    hipLaunchKernelGGL(k_base_shared_check, dim3(64, g.members - 1, nplanes), dim3(256), 0, s, g, base, differs);
+}
+
 void launch_coe_compare(const Grid& g, const float* x, const float* y, unsigned* differs, hipStream_t s)
 {
     (void)hipMemsetAsync(differs, 0, sizeof(unsigned), s);

@@ -179,7 +179,10 @@ __device__ __forceinline__ bool fast_tile(const Grid& g, const TileGeom& tg, flo
         // clamped (always valid) address; what lies outside the domain is replaced afterwards.  Row offsets are
         // scalar (the wave index is), the only per-lane part of an address is the column.
         const rsrc_t pr = plane_rsrc(psi_in + mo, g), fr = plane_rsrc(f + mo, g);
-        const rsrc_t apr = plane_rsrc(base + mo, g), cqr = plane_rsrc(base + ks + mo, g);
+        // (generating planes that all members share are read from member 0's copy: Grid.base_shared)
+        const size_t mo_a = (g.base_shared & 1) ? 0 : mo, mo_c = (g.base_shared & 2) ? 0 : mo, mo_x = (g.base_shared & 4) ? 0 : mo, mo_y = (g.base_shared & 8) ? 0 : mo;
+        (void)mo_x; (void)mo_y;
+        const rsrc_t apr = plane_rsrc(base + mo_a, g), cqr = plane_rsrc(base + ks + mo_c, g);
         const int cx = (INNER ? gx : (gx < 0 ? 0 : (gx > g.nx - 1 ? g.nx - 1 : gx))) * 4;
         auto rowoff = [&](int gy) -> int {
             const int cy = INNER ? gy : (gy < 0 ? 0 : (gy > g.ny - 1 ? g.ny - 1 : gy));
@@ -189,7 +192,7 @@ __device__ __forceinline__ bool fast_tile(const Grid& g, const TileGeom& tg, flo
         const int ob = rowoff(gy0 - 1);
         const float rcq_b = bload(cqr, cx, ob);
         float rby_b = 0.0f;
-        if constexpr (!BARO) rby_b = bload(plane_rsrc(base + 3 * ks + mo, g), cx, ob);
+        if constexpr (!BARO) rby_b = bload(plane_rsrc(base + 3 * ks + mo_y, g), cx, ob);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int o = rowoff(gy0 + r);
@@ -198,8 +201,8 @@ __device__ __forceinline__ bool fast_tile(const Grid& g, const TileGeom& tg, flo
             rap[r] = bload(apr, cx, o);
             rcq[r] = bload(cqr, cx, o);
             if constexpr (!BARO) {
-                rbx[r] = bload(plane_rsrc(base + 2 * ks + mo, g), cx, o);
-                rby[r] = bload(plane_rsrc(base + 3 * ks + mo, g), cx, o);
+                rbx[r] = bload(plane_rsrc(base + 2 * ks + mo_x, g), cx, o);
+                rby[r] = bload(plane_rsrc(base + 3 * ks + mo_y, g), cx, o);
             }
         }
         stamp<STAMP>(tg, 1);                                // loads issued
@@ -511,10 +514,10 @@ __device__ __forceinline__ void exact_tile(const Grid& g, const TileGeom& tg, fl
     {
         const float* __restrict__ pm = psi_in + mo;
         const float* __restrict__ fm = f + mo;
-        const float* __restrict__ apm = base + mo;
-        const float* __restrict__ cqm = base + ks + mo;
-        const float* __restrict__ bxm = base + 2 * ks + mo;
-        const float* __restrict__ bym = base + 3 * ks + mo;
+        const float* __restrict__ apm = base + ((g.base_shared & 1) ? 0 : mo);
+        const float* __restrict__ cqm = base + ks + ((g.base_shared & 2) ? 0 : mo);
+        const float* __restrict__ bxm = base + 2 * ks + ((g.base_shared & 4) ? 0 : mo);
+        const float* __restrict__ bym = base + 3 * ks + ((g.base_shared & 8) ? 0 : mo);
         const unsigned cx = (unsigned)(gx < 0 ? 0 : (gx > g.nx - 1 ? g.nx - 1 : gx));
         auto rowoff = [&](int gy) -> size_t {
             const int cy = gy < 0 ? 0 : (gy > g.ny - 1 ? g.ny - 1 : gy);

@@ -109,11 +109,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     constexpr int U = S;
     constexpr int W = 64 - 2 * T;
     static_assert(W % 4 == 0 && U % 2 == 0 && U % S == 0, "the 16-byte stores take the strip's own columns in fours");
-    constexpr int NPL = 3;                                // f, AP, CQ
-    constexpr int NG = 3, NGP = 4;                        // groups in LDS: the weights' planes / psi (the group before stays for its two rows)
-    constexpr int NF = NPL + 1;                           // fetch instructions per group
-    __shared__ __attribute__((aligned(16))) float fring[NG][NPL][2][2][64];
-    __shared__ __attribute__((aligned(16))) float pring[NGP][2][2][64];
+    constexpr int NF = 4;                                 // fetch instructions per group: psi, f, AP, CQ
+    constexpr int DG = 3;                                 // groups in flight ahead of the one being read
+    constexpr int NG = DG + 1;                            // groups in LDS
+    __shared__ __attribute__((aligned(16))) float ring[NG][NF][2][2][64];   // [group][plane][chunk][row][column]: 4 KB per group
     __shared__ __attribute__((aligned(16))) float obuf[2][2][64];
     const int lane = threadIdx.x;
     const int part = (int)gridDim.x >> 3;                 // (the grid is a multiple of eight: workgroup b runs on XCD b % 8)
@@ -130,7 +129,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const bool col_int = gx >= 1 && gx <= g.nx - 2;
     const int nvalid = (g.nx - 2 - s * W) < W ? (g.nx - 2 - s * W) : W;
     const size_t mo = (size_t)m * g.plane, ks = g.kstride ? g.kstride : (size_t)g.members * g.plane;
-    const rsrc_t pr = zrsrc(psi_in + mo, g, 16), fr = zrsrc(f + mo, g, 16), apr = zrsrc(base + mo, g, 16), cqr = zrsrc(base + ks + mo, g, 16);
+    // (generating planes that all members share are read from member 0's copy: Grid.base_shared)
+    const rsrc_t pr = zrsrc(psi_in + mo, g, 16), fr = zrsrc(f + mo, g, 16);
+    const rsrc_t apr = zrsrc(base + ((g.base_shared & 1) ? 0 : mo), g, 16), cqr = zrsrc(base + ks + ((g.base_shared & 2) ? 0 : mo), g, 16);
     const rsrc_t outr = zrsrc(psi_out + mo, g);
     const int ya = 1 + c * Lc, yb = 1 + (c + P) * Lc;
     const int yend_a = ya + Lc < g.ny - 1 ? ya + Lc : g.ny - 1, yend_b = yb + Lc < g.ny - 1 ? yb + Lc : g.ny - 1;
@@ -139,14 +140,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     typedef __attribute__((address_space(3))) void* lds_t;
     // this lane's part of a fetch: row (lane >> 4) & 1 of the group, of chunk lane >> 5, 16 bytes from column x0 + 4 (lane & 15)
     const int fy = (lane >= 32 ? yb : ya) + ((lane >> 4) & 1), fcol4 = (x0 + 4 * (lane & 15)) * 4;
-    auto fetch = [&](int r0, int fs, int ps) {
+    auto fetch = [&](int r0, int gs) {
         int ry = fy + r0;
         ry = ry < 0 ? 0 : (ry > g.ny - 1 ? g.ny - 1 : ry);
         const int o = ry * pitch4 + fcol4;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(pr, (lds_t)&pring[ps][0][0][0], 16, o, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(fr, (lds_t)&fring[fs][0][0][0][0], 16, o, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(apr, (lds_t)&fring[fs][1][0][0][0], 16, o, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(cqr, (lds_t)&fring[fs][2][0][0][0], 16, o, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(pr, (lds_t)&ring[gs][0][0][0][0], 16, o, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(fr, (lds_t)&ring[gs][1][0][0][0], 16, o, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(apr, (lds_t)&ring[gs][2][0][0][0], 16, o, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(cqr, (lds_t)&ring[gs][3][0][0][0], 16, o, 0, 0, 0);
+    };
+    // One tick's row of the four planes from LDS: issued a tick ahead, into `nx`, and waited for at that tick's end, so that the
+    // LDS latency hides behind a tick of arithmetic.  Inline assembly: the compiler cannot tell the slot an LDS-DMA fetch
+    // fills from the slot read here and would drain vmcnt(0) in front of every read of this array that it can see (measured:
+    // 15.7 -> 22.6 us).  [chunk][row][64]: row r of chunk a at offset r (x 64 dwords), of chunk b at 2 + r; plane k at 4 k.
+    struct Row { f2 p, f, a, c; };
+    auto lds_issue = [&](Row& nx, int gs, auto sub_tag) {
+        constexpr int r = decltype(sub_tag)::value;
+        const unsigned ad = (unsigned)(size_t)(lds_t)&ring[gs][0][0][0][lane];
+        asm volatile("ds_read2st64_b32 %0, %4 offset0:%5 offset1:%6\n\t"
+                     "ds_read2st64_b32 %1, %4 offset0:%7 offset1:%8\n\t"
+                     "ds_read2st64_b32 %2, %4 offset0:%9 offset1:%10\n\t"
+                     "ds_read2st64_b32 %3, %4 offset0:%11 offset1:%12"
+                     : "=&v"(nx.p), "=&v"(nx.f), "=&v"(nx.a), "=&v"(nx.c)
+                     : "v"(ad), "n"(r), "n"(r + 2), "n"(r + 4), "n"(r + 6), "n"(r + 8), "n"(r + 10), "n"(r + 12), "n"(r + 14) : "memory");
+    };
+    auto lds_wait = [&](Row& nx) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nx.p), "+v"(nx.f), "+v"(nx.a), "+v"(nx.c) : : "memory");
     };
 
     // stores: lane l < 4 GC carries columns 4 (l % GC) .. + 3 of row (l / GC) & 1 of chunk l / (2 GC) of a group of two result rows
@@ -182,11 +201,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
         for (int l = 0; l < T; ++l) hist[l][0] = hist[l][1] = f2{0.f, 0.f};
         bool bad = false;
-        pring[NGP - 1][0][0][lane] = 0.0f; pring[NGP - 1][0][1][lane] = 0.0f;   // the psi rows "before the first": zeros
-        pring[NGP - 1][1][0][lane] = 0.0f; pring[NGP - 1][1][1][lane] = 0.0f;
-        int fs = 0, ps = 0;
-        fetch(j_first, 0, 0);
-        fetch(j_first + 2, 1, 1);
+        int cs = 0;                                       // ring slot of the group the current tick's row is in
+#pragma unroll
+        for (int d = 0; d < DG; ++d) fetch(j_first + 2 * d, d);
+        Row nx;                                           // the next tick's row
+        f2 pv1 = f2{0.f, 0.f}, pv2 = f2{0.f, 0.f};        // psi of the two rows before (the rows "before the first": zeros -- they
+                                                          // only reach values that are never stored)
+        __builtin_amdgcn_s_waitcnt((((DG - 1) * NF) & 0xf) | (0x7 << 4) | (0xf << 8));   // the first group has landed
+        lds_issue(nx, 0, std::integral_constant<int, 0>{});
+        lds_wait(nx);
         for (int j0 = 0; j0 < n_ticks; j0 += U) {
             z_for<U>([&](auto uc) {
                 constexpr int u = decltype(uc)::value;
@@ -195,34 +218,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 const int jr = j_first + j0 + u;
                 const int rowa = ya + jr, rowb = yb + jr;
                 constexpr int slot = u % S, q = u & 1;
-                if constexpr (sub == 0) {
-                    // the group after the next goes out, then this one must have landed: at most the 2 NF younger fetches may
-                    // be in flight (loads retire in order among themselves; stores only make the count larger)
-                    const int fn = fs + 2 >= NG ? fs + 2 - NG : fs + 2, pn = ps + 2 >= NGP ? ps + 2 - NGP : ps + 2;
-                    fetch(jr + 4, fn, pn);
-                    __builtin_amdgcn_s_waitcnt(((2 * NF) & 0xf) | (0x7 << 4) | (0xf << 8));   // vmcnt(2 NF): 8 or 12
-                }
-                f2 p0, p1, p2, fa, ap, cq;
+                const f2 p0 = nx.p, fa = nx.f, ap = nx.a, cq = nx.c, p1 = pv1, p2 = pv2;
                 const f2 bx = f2{0.f, 0.f}, by = f2{0.f, 0.f};   // (b = 0: what the exact body's nine weights are made of besides AP, CQ)
-                {
-                    const int pm = ps >= 1 ? ps - 1 : NGP - 1;
-                    const unsigned aP = (unsigned)(size_t)(lds_t)&pring[ps][0][0][lane], aM = (unsigned)(size_t)(lds_t)&pring[pm][0][0][lane];
-                    const unsigned aF = (unsigned)(size_t)(lds_t)&fring[fs][0][0][0][lane];
-                    // [chunk][row][64]: row r of chunk a at offset r (x 64 dwords), of chunk b at 2 + r; plane k of fring at 4 k
-                    // row jr - 1: this group's row 0 (sub = 1) or the group before's row 1; row jr - 2: the group before's row sub
-                    asm volatile("ds_read2st64_b32 %0, %6 offset0:%9 offset1:%10\n\t"
-                                 "ds_read2st64_b32 %1, %7 offset0:%11 offset1:%12\n\t"
-                                 "ds_read2st64_b32 %2, %8 offset0:%9 offset1:%10\n\t"
-                                 "ds_read2st64_b32 %3, %13 offset0:%9 offset1:%10\n\t"
-                                 "ds_read2st64_b32 %4, %13 offset0:%14 offset1:%15\n\t"
-                                 "ds_read2st64_b32 %5, %13 offset0:%16 offset1:%17\n\t"
-                                 "s_waitcnt lgkmcnt(0)"
-                                 : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(fa), "=&v"(ap), "=&v"(cq)
-                                 : "v"(aP), "v"(sub == 1 ? aP : aM), "v"(aM),
-                                   "n"(sub), "n"(sub + 2), "n"(1 - sub), "n"(3 - sub),
-                                   "v"(aF), "n"(sub + 4), "n"(sub + 6), "n"(sub + 8), "n"(sub + 10) : "memory");
+                if constexpr (sub == 0) {
+                    // a group starts: the slot of the group before it is free (its last row was read two ticks ago) and takes the
+                    // group DG ahead; the next tick's row is this group's second, in LDS since this group's first was read
+                    fetch(jr + 2 * DG, cs >= 1 ? cs - 1 : NG - 1);
+                    lds_issue(nx, cs, std::integral_constant<int, 1>{});
+                } else {
+                    // the next tick's row is the first of the next group: that group must have landed -- at most the DG - 1 younger
+                    // ones may be in flight (loads retire in order among themselves; stores only make the count larger)
+                    __builtin_amdgcn_s_waitcnt((((DG - 1) * NF) & 0xf) | (0x7 << 4) | (0xf << 8));
+                    cs = cs + 1 >= NG ? 0 : cs + 1;
+                    lds_issue(nx, cs, std::integral_constant<int, 0>{});
                 }
-                if constexpr (sub == 1) { fs = fs + 1 >= NG ? 0 : fs + 1; ps = ps + 1 >= NGP ? 0 : ps + 1; }
+                // (between the issue and the wait nothing may touch nx's registers -- the hardware does not interlock them.  The
+                // optimistic body keeps them apart for a whole tick; tests/test_sweepz_isa.py reads the compiled code to see that no
+                // instruction got in between.  The exact body, whose register pressure invites copies, waits at once.)
+                if constexpr (EXACT) lds_wait(nx);
                 if constexpr (!EXACT)
                     bad = bad || __builtin_bit_cast(unsigned, p0.x) == 0x80000000u || __builtin_bit_cast(unsigned, p0.y) == 0x80000000u;
                 f2 up = p0;
@@ -319,6 +332,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 if constexpr (EXACT) y1[slot] = f2{ia ? 1.0f : 0.0f, ib ? 1.0f : 0.0f};
                 else y1[slot] = f2{ia ? quotient_y1(-c5.x) : -0.0f, ib ? quotient_y1(-c5.y) : -0.0f};
                 ff[slot] = fa;
+                pv2 = pv1; pv1 = p0;
+                if constexpr (!EXACT) lds_wait(nx);       // the next tick's row has arrived (LDS returns in order)
             });
         }
         __builtin_amdgcn_s_waitcnt((0x7 << 4) | (0xf << 8));   // vmcnt(0): the fetches past the end have landed before LDS is used again

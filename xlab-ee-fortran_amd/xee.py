@@ -55,7 +55,7 @@ class Timing(C.Structure):
     _fields_ = [("solve_ms", C.c_double), ("sweep_ms", C.c_double), ("sweep_launches", C.c_int64),
                 ("iterations", C.c_int64), ("check_launches", C.c_int64), ("redo_tiles", C.c_int64),
                 ("inline_redo_tiles", C.c_int64), ("tiles", C.c_int64), ("sweep_streams", C.c_int64), ("z_launches", C.c_int64),
-                ("z_ms", C.c_double), ("z_timed_launches", C.c_int64)]
+                ("z_ms", C.c_double), ("z_timed_launches", C.c_int64), ("shared_planes", C.c_int64)]
 
 
 _lib = None
