@@ -153,19 +153,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // LDS latency hides behind a tick of arithmetic.  Inline assembly: the compiler cannot tell the slot an LDS-DMA fetch
     // fills from the slot read here and would drain vmcnt(0) in front of every read of this array that it can see (measured:
     // 15.7 -> 22.6 us).  [chunk][row][64]: row r of chunk a at offset r (x 64 dwords), of chunk b at 2 + r; plane k at 4 k.
-    struct Row { f2 p, f, a, c; };
-    auto lds_issue = [&](Row& nx, int gs, auto sub_tag) {
+    struct Fac { f2 f, a, c; };
+    auto lds_issue = [&](f2& np, Fac& nx, int gs, auto sub_tag) {
         constexpr int r = decltype(sub_tag)::value;
         const unsigned ad = (unsigned)(size_t)(lds_t)&ring[gs][0][0][0][lane];
         asm volatile("ds_read2st64_b32 %0, %4 offset0:%5 offset1:%6\n\t"
                      "ds_read2st64_b32 %1, %4 offset0:%7 offset1:%8\n\t"
                      "ds_read2st64_b32 %2, %4 offset0:%9 offset1:%10\n\t"
                      "ds_read2st64_b32 %3, %4 offset0:%11 offset1:%12"
-                     : "=&v"(nx.p), "=&v"(nx.f), "=&v"(nx.a), "=&v"(nx.c)
+                     : "=&v"(np), "=&v"(nx.f), "=&v"(nx.a), "=&v"(nx.c)
                      : "v"(ad), "n"(r), "n"(r + 2), "n"(r + 4), "n"(r + 6), "n"(r + 8), "n"(r + 10), "n"(r + 12), "n"(r + 14) : "memory");
     };
-    auto lds_wait = [&](Row& nx) {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nx.p), "+v"(nx.f), "+v"(nx.a), "+v"(nx.c) : : "memory");
+    // (the pending registers are INPUTS of the waiting statement: that keeps them reserved until the data is there -- with no
+    // operands the compiler reused the registers of a tick's unused last read as temporaries while the read was in flight -- and
+    // asks for no copy -- as tied in/out operands they were copied, still pending, to wherever the "results" were wanted.  Nothing may
+    // be scheduled across the wait; tests/test_sweepz_isa.py checks what came out.)
+    auto lds_wait = [&](const f2& np, const Fac& nx) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" : : "v"(np), "v"(nx.f), "v"(nx.a), "v"(nx.c) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
     };
 
     // stores: lane l < 4 GC carries columns 4 (l % GC) .. + 3 of row (l / GC) & 1 of chunk l / (2 GC) of a group of two result rows
@@ -204,38 +210,44 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         int cs = 0;                                       // ring slot of the group the current tick's row is in
 #pragma unroll
         for (int d = 0; d < DG; ++d) fetch(j_first + 2 * d, d);
-        Row nx;                                           // the next tick's row
-        f2 pv1 = f2{0.f, 0.f}, pv2 = f2{0.f, 0.f};        // psi of the two rows before (the rows "before the first": zeros -- they
-                                                          // only reach values that are never stored)
+        // The rows in registers rotate through fixed places -- psi of ticks u, u - 1, u - 2 in psr[u & 3], psr[(u + 3) & 3],
+        // psr[(u + 2) & 3], the next tick's into psr[(u + 1) & 3]; f, AP, CQ of tick u in fac[u & 1] -- so that no tick moves a value
+        // (a turn of the unrolled loop is a multiple of four ticks).  The rows "before the first": zeros (they only reach values
+        // that are never stored).
+        f2 psr[4] = {f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}};
+        Fac fac[2];
         __builtin_amdgcn_s_waitcnt((((DG - 1) * NF) & 0xf) | (0x7 << 4) | (0xf << 8));   // the first group has landed
-        lds_issue(nx, 0, std::integral_constant<int, 0>{});
-        lds_wait(nx);
-        for (int j0 = 0; j0 < n_ticks; j0 += U) {
-            z_for<U>([&](auto uc) {
+        lds_issue(psr[0], fac[0], 0, std::integral_constant<int, 0>{});
+        lds_wait(psr[0], fac[0]);
+        int j0 = 0;
+        auto tick = [&](auto uc, auto guard_tag) {
                 constexpr int u = decltype(uc)::value;
                 constexpr int sub = u & 1;
-                if (j0 + u >= n_ticks) return;            // (the last turn of the unrolled loop ends where the walk does)
+                if constexpr (decltype(guard_tag)::value) { if (j0 + u >= n_ticks) return; }   // (the last, partial turn ends where the walk does)
                 const int jr = j_first + j0 + u;
                 const int rowa = ya + jr, rowb = yb + jr;
                 constexpr int slot = u % S, q = u & 1;
-                const f2 p0 = nx.p, fa = nx.f, ap = nx.a, cq = nx.c, p1 = pv1, p2 = pv2;
+                const f2 p0 = psr[u & 3], p1 = psr[(u + 3) & 3], p2 = psr[(u + 2) & 3];
+                const f2 fa = fac[u & 1].f, ap = fac[u & 1].a, cq = fac[u & 1].c;
+                f2& np = psr[(u + 1) & 3];                // where the next tick's row goes
+                Fac& nx = fac[(u + 1) & 1];
                 const f2 bx = f2{0.f, 0.f}, by = f2{0.f, 0.f};   // (b = 0: what the exact body's nine weights are made of besides AP, CQ)
                 if constexpr (sub == 0) {
                     // a group starts: the slot of the group before it is free (its last row was read two ticks ago) and takes the
                     // group DG ahead; the next tick's row is this group's second, in LDS since this group's first was read
                     fetch(jr + 2 * DG, cs >= 1 ? cs - 1 : NG - 1);
-                    lds_issue(nx, cs, std::integral_constant<int, 1>{});
+                    lds_issue(np, nx, cs, std::integral_constant<int, 1>{});
                 } else {
                     // the next tick's row is the first of the next group: that group must have landed -- at most the DG - 1 younger
                     // ones may be in flight (loads retire in order among themselves; stores only make the count larger)
                     __builtin_amdgcn_s_waitcnt((((DG - 1) * NF) & 0xf) | (0x7 << 4) | (0xf << 8));
                     cs = cs + 1 >= NG ? 0 : cs + 1;
-                    lds_issue(nx, cs, std::integral_constant<int, 0>{});
+                    lds_issue(np, nx, cs, std::integral_constant<int, 0>{});
                 }
                 // (between the issue and the wait nothing may touch nx's registers -- the hardware does not interlock them.  The
                 // optimistic body keeps them apart for a whole tick; tests/test_sweepz_isa.py reads the compiled code to see that no
                 // instruction got in between.  The exact body, whose register pressure invites copies, waits at once.)
-                if constexpr (EXACT) lds_wait(nx);
+                if constexpr (EXACT) lds_wait(np, nx);
                 if constexpr (!EXACT)
                     bad = bad || __builtin_bit_cast(unsigned, p0.x) == 0x80000000u || __builtin_bit_cast(unsigned, p0.y) == 0x80000000u;
                 f2 up = p0;
@@ -332,10 +344,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 if constexpr (EXACT) y1[slot] = f2{ia ? 1.0f : 0.0f, ib ? 1.0f : 0.0f};
                 else y1[slot] = f2{ia ? quotient_y1(-c5.x) : -0.0f, ib ? quotient_y1(-c5.y) : -0.0f};
                 ff[slot] = fa;
-                pv2 = pv1; pv1 = p0;
-                if constexpr (!EXACT) lds_wait(nx);       // the next tick's row has arrived (LDS returns in order)
-            });
-        }
+                if constexpr (!EXACT) lds_wait(np, nx);   // the next tick's row has arrived (LDS returns in order)
+        };
+        // whole turns of the unrolled loop run without a test per tick (a test makes every tick a basic block of its own, and the
+        // values that live across ticks were shuffled at each boundary: 19 moves per tick), the last, partial turn with one
+        for (; j0 + U <= n_ticks; j0 += U) z_for<U>([&](auto uc) { tick(uc, std::false_type{}); });
+        if (j0 < n_ticks) z_for<U>([&](auto uc) { tick(uc, std::true_type{}); });
         __builtin_amdgcn_s_waitcnt((0x7 << 4) | (0xf << 8));   // vmcnt(0): the fetches past the end have landed before LDS is used again
         return __builtin_amdgcn_ballot_w64(bad) == 0;
     };
