@@ -123,3 +123,51 @@ def test_streamed_large_batch_with_a_shared_operator_against_the_reference_files
     assert t0["shared_planes"] == 0 and biteq(psi, p0) and rec["err_now"].tobytes() == r0["err_now"].tobytes()
     for m in (1, 2, 3, 7):
         assert H.md5(psi[m]) == gold[f"member{m}_1024x512_200"]["md5"]["rchi-[BAROTROPIC]-O.bin"], m
+
+
+def test_member_pairs_walk_special_values_and_exact_body():
+    """Where all members share AP and CQ, k_sweep_z walks the same chunk of TWO members in the two halves of its register pairs
+    (an odd last member with itself).  Three members: one plain, one with -0 on its rim and inside its first guess, one whose
+    first guess overflows -- the wave that holds the -0 / the non-finite value takes the exact body for BOTH its members; and the
+    exact body alone; against the tiled sweep and against the chunk-paired walk (share_planes = 0)."""
+    nr, nz, n = 170, 110, 40
+    A, B, Cc, bc = H.rich_inputs(nr, nz, seed=23)
+    rng = np.random.default_rng(8)
+    f = ((0.5 + rng.random(A.shape)) * rng.choice([-1e-6, 1e-6], size=A.shape)).astype(np.float32)
+    b1 = bc.copy(); b1[0, 60:64] = np.float32(-0.0); b1[50:52, 80:90] = np.float32(-0.0); b1[nz - 1, 100] = np.float32(-0.0)
+    b2 = bc.copy(); b2[30:33, 40:50] = np.float32(3.0e38)
+    mem = [(A, B, Cc, bc), (A, B, Cc, b1), (A, B, Cc, b2)]
+
+    def run(opts):
+        with xee.Ensemble(nr, nz, 3) as e:
+            for k, v in opts.items():
+                e.set_option(k, v)
+            e.set_profiles(xee.profiles(nr, nz))
+            for m, (a_, b_, c_, bc_) in enumerate(mem):
+                for name, arr in (("A", a_), ("B", b_), ("C", c_), ("BC_INIT", bc_), ("FORCING", f * np.float32(1 + m))):
+                    e.upload(name, arr, first=m)
+            e.assemble(0)
+            with np.errstate(all="ignore"):
+                rec = e.solve(n, 1e-8, -1.0, 1.0)
+            return e.download("PSI"), rec, e.timing(), e.sweep_info()
+
+    want, rw, tw, _ = run({"kernel": 3})
+    assert not np.all(np.isfinite(want[2])) and np.all(np.isfinite(want[0])) and np.all(np.isfinite(want[1]))
+    for opts in ({"kernel": 4}, {"kernel": 4, "q_exact_only": 1}, {"kernel": 4, "share_planes": 0}, {"kernel": 4, "z_pairs": 3}):
+        got, rg, t, info = run(opts)
+        assert t["z_launches"] > 0 and t["shared_planes"] == (0 if opts.get("share_planes") == 0 else AP | CQ)
+        assert t["inline_redo_tiles"] > 0
+        assert biteq(got[:2], want[:2]), opts                        # the finite members: bit for bit
+        nan = np.isnan(want[2])
+        assert np.array_equal(np.isnan(got[2]), nan) and np.array_equal(got[2].view(np.uint32)[~nan], want[2].view(np.uint32)[~nan]), opts
+        assert np.signbit(got[1][0, 60]) and got[1][0, 60] == 0.0    # the rim keeps its -0
+
+
+@pytest.mark.parametrize("M", [2, 3, 7, 8])
+def test_member_pairs_every_member_count(M):
+    nr, nz, n = 120, 75, 130
+    mem = _members(nr, nz, M, "B")
+    psi, rec, t = _solve(mem, 0, n, {"kernel": 4})
+    assert t["z_launches"] > 0 and t["shared_planes"] == (AP | CQ) and t["inline_redo_tiles"] == 0
+    ref, rr, _ = _solve(mem, 0, n, {"kernel": 3, "share_planes": 0})
+    assert biteq(psi, ref) and rec["err_now"].tobytes() == rr["err_now"].tobytes() and rec["iters"].tolist() == rr["iters"].tolist()

@@ -83,6 +83,13 @@ __device__ __forceinline__ f2 z_q2(f2 a, f2 nd, f2 y1)   // a / d with y1 = quot
     return __builtin_elementwise_fma(r1, y1, q1);
 }
 
+// a weight is a pair (one value per chunk) or, where both halves of the register pair work on the SAME rows of two members that
+// share their operator, one value for both
+__device__ __forceinline__ f2 b2(f2 v) { return v; }
+__device__ __forceinline__ f2 b2(float v) { return f2{v, v}; }
+__device__ __forceinline__ f2 zshrW(f2 v) { return zshr2(v); }
+__device__ __forceinline__ float zshrW(float v) { return zshr1(v); }
+
 // compile-time loops: body(std::integral_constant<int, i>{}) for i = 0 .. N-1 (indices into the register arrays must be
 // constants: with a run-time index, or a loop the compiler does not unroll, the arrays live in scratch memory)
 template <class F, int... Is>
@@ -98,7 +105,11 @@ __device__ __forceinline__ void z_for(F&& body) { z_for_impl(body, std::make_int
 // Fetch groups of TWO rows: one 16-byte LDS-DMA instruction per plane and group -- lanes 0..31 carry rows r, r + 1 of chunk a,
 // lanes 32..63 those of chunk b (16 lanes x 16 bytes = the 64 columns of a row) -- landing as [chunk][row][64] in LDS, two
 // groups ahead of the walk.  (Groups of four rows, one group ahead, 20 KB: the same speed.)
-template <int T>
+// MP ("member pairs"; the launcher chooses it where all members share AP and CQ): the two halves of the register pair are the SAME
+// chunk of TWO members instead of two chunks of one -- the weights of a row (AP, CQ, coe5, y1) then are one value for both halves:
+// half the registers and half the arithmetic to make them, three fetches per group instead of four (AP and CQ share one: lanes
+// 0..31 AP's two rows, lanes 32..63 CQ's), 3 KB of LDS per group and so one more group in flight.
+template <int T, bool MP>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sweep_z(Grid g, const float* __restrict__ psi_in, float* __restrict__ psi_out,
         const float* __restrict__ base, const float* __restrict__ f, const MemberState* __restrict__ st, int nstrip, int P, int Lc, int nunits,
         int exact_only, int* __restrict__ diag)
@@ -109,19 +120,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     constexpr int U = S;
     constexpr int W = 64 - 2 * T;
     static_assert(W % 4 == 0 && U % 2 == 0 && U % S == 0, "the 16-byte stores take the strip's own columns in fours");
-    constexpr int NF = 4;                                 // fetch instructions per group: psi, f, AP, CQ
-    constexpr int DG = 3;                                 // groups in flight ahead of the one being read
+    constexpr int NF = MP ? 3 : 4;                        // fetch instructions per group: psi, f, AP, CQ (MP: AP and CQ in one)
+    constexpr int DG = MP ? 4 : 3;                        // groups in flight ahead of the one being read
     constexpr int NG = DG + 1;                            // groups in LDS
-    __shared__ __attribute__((aligned(16))) float ring[NG][NF][2][2][64];   // [group][plane][chunk][row][column]: 4 KB per group
+    __shared__ __attribute__((aligned(16))) float ring[NG][NF][2][2][64];   // [group][plane][chunk or member][row][column]: 4 KB (MP: 3 KB) per group
     __shared__ __attribute__((aligned(16))) float obuf[2][2][64];
     const int lane = threadIdx.x;
     const int part = (int)gridDim.x >> 3;                 // (the grid is a multiple of eight: workgroup b runs on XCD b % 8)
     const int wv = ((int)blockIdx.x & 7) * part + ((int)blockIdx.x >> 3);
     if (wv >= nunits) return;
-    const int per_member = nstrip * P;
-    const int m = wv / per_member;
-    if (st && !st[m].active) return;
-    const int rem = wv - m * per_member;
+    // units: strip fastest, then chunk pair (MP: chunk), then member (MP: pair of members; an odd last member pairs with itself)
+    const int per_member = nstrip * (MP ? 2 * P : P);
+    const int mu = wv / per_member;
+    const int m = MP ? 2 * mu : mu, mb = MP ? (m + 1 < g.members ? m + 1 : m) : m;
+    if (st && !st[m].active && !st[mb].active) return;  // (MP: a stopped member beside a running one is iterated on: its result is its snapshot's)
+    const int rem = wv - mu * per_member;
     const int s = rem % nstrip, c = rem / nstrip;
     const int lo = s == 0 ? 1 : T;
     const int x0 = s * W + 1 - lo;                        // column of lane 0
@@ -130,33 +143,47 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int nvalid = (g.nx - 2 - s * W) < W ? (g.nx - 2 - s * W) : W;
     const size_t mo = (size_t)m * g.plane, ks = g.kstride ? g.kstride : (size_t)g.members * g.plane;
     // (generating planes that all members share are read from member 0's copy: Grid.base_shared)
-    const rsrc_t pr = zrsrc(psi_in + mo, g, 16), fr = zrsrc(f + mo, g, 16);
-    const rsrc_t apr = zrsrc(base + ((g.base_shared & 1) ? 0 : mo), g, 16), cqr = zrsrc(base + ks + ((g.base_shared & 2) ? 0 : mo), g, 16);
-    const rsrc_t outr = zrsrc(psi_out + mo, g);
-    const int ya = 1 + c * Lc, yb = 1 + (c + P) * Lc;
+    // (MP: one descriptor spans both members' planes -- the second half's lanes add dmo4 bytes -- and AP's descriptor spans up to CQ)
+    const int dmo4 = (int)((size_t)(mb - m) * g.plane * 4);
+    const int dcq4 = MP ? (int)(ks * 4) : 0;
+    const rsrc_t pr = zrsrc(psi_in + mo, g, 16 + dmo4), fr = zrsrc(f + mo, g, 16 + dmo4);
+    const rsrc_t apr = zrsrc(base + ((g.base_shared & 1) ? 0 : mo), g, 16 + dcq4), cqr = zrsrc(base + ks + ((g.base_shared & 2) ? 0 : mo), g, 16);
+    const rsrc_t outr = zrsrc(psi_out + mo, g, dmo4);
+    const int ya = 1 + c * Lc, yb = MP ? ya : 1 + (c + P) * Lc;
     const int yend_a = ya + Lc < g.ny - 1 ? ya + Lc : g.ny - 1, yend_b = yb + Lc < g.ny - 1 ? yb + Lc : g.ny - 1;
     const int pitch4 = g.pitch * 4;
 
     typedef __attribute__((address_space(3))) void* lds_t;
     // this lane's part of a fetch: row (lane >> 4) & 1 of the group, of chunk lane >> 5, 16 bytes from column x0 + 4 (lane & 15)
     const int fy = (lane >= 32 ? yb : ya) + ((lane >> 4) & 1), fcol4 = (x0 + 4 * (lane & 15)) * 4;
+    const int fhalf = lane >= 32 ? dmo4 : 0, fac4 = lane >= 32 ? dcq4 : 0;   // MP: the second half's member / CQ behind AP
     auto fetch = [&](int r0, int gs) {
         int ry = fy + r0;
         ry = ry < 0 ? 0 : (ry > g.ny - 1 ? g.ny - 1 : ry);
         const int o = ry * pitch4 + fcol4;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(pr, (lds_t)&ring[gs][0][0][0][0], 16, o, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(fr, (lds_t)&ring[gs][1][0][0][0], 16, o, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(apr, (lds_t)&ring[gs][2][0][0][0], 16, o, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(cqr, (lds_t)&ring[gs][3][0][0][0], 16, o, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(pr, (lds_t)&ring[gs][0][0][0][0], 16, o + fhalf, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(fr, (lds_t)&ring[gs][1][0][0][0], 16, o + fhalf, 0, 0, 0);
+        if constexpr (MP) __builtin_amdgcn_raw_ptr_buffer_load_lds(apr, (lds_t)&ring[gs][2][0][0][0], 16, o + fac4, 0, 0, 0);
+        else {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(apr, (lds_t)&ring[gs][2][0][0][0], 16, o, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(cqr, (lds_t)&ring[gs][NF - 1][0][0][0], 16, o, 0, 0, 0);
+        }
     };
     // One tick's row of the four planes from LDS: issued a tick ahead, into `nx`, and waited for at that tick's end, so that the
     // LDS latency hides behind a tick of arithmetic.  Inline assembly: the compiler cannot tell the slot an LDS-DMA fetch
     // fills from the slot read here and would drain vmcnt(0) in front of every read of this array that it can see (measured:
     // 15.7 -> 22.6 us).  [chunk][row][64]: row r of chunk a at offset r (x 64 dwords), of chunk b at 2 + r; plane k at 4 k.
-    struct Fac { f2 f, a, c; };
+    struct Fac { f2 f, a, c; };                           // (MP: a = {AP, CQ} of the row, c unused)
     auto lds_issue = [&](f2& np, Fac& nx, int gs, auto sub_tag) {
         constexpr int r = decltype(sub_tag)::value;
         const unsigned ad = (unsigned)(size_t)(lds_t)&ring[gs][0][0][0][lane];
+        if constexpr (MP)
+            asm volatile("ds_read2st64_b32 %0, %3 offset0:%4 offset1:%5\n\t"
+                         "ds_read2st64_b32 %1, %3 offset0:%6 offset1:%7\n\t"
+                         "ds_read2st64_b32 %2, %3 offset0:%8 offset1:%9"
+                         : "=&v"(np), "=&v"(nx.f), "=&v"(nx.a)
+                         : "v"(ad), "n"(r), "n"(r + 2), "n"(r + 4), "n"(r + 6), "n"(r + 8), "n"(r + 10) : "memory");
+        else
         asm volatile("ds_read2st64_b32 %0, %4 offset0:%5 offset1:%6\n\t"
                      "ds_read2st64_b32 %1, %4 offset0:%7 offset1:%8\n\t"
                      "ds_read2st64_b32 %2, %4 offset0:%9 offset1:%10\n\t"
@@ -170,7 +197,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // be scheduled across the wait; tests/test_sweepz_isa.py checks what came out.)
     auto lds_wait = [&](const f2& np, const Fac& nx) {
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" : : "v"(np), "v"(nx.f), "v"(nx.a), "v"(nx.c) : "memory");
+        if constexpr (MP) asm volatile("s_waitcnt lgkmcnt(0)" : : "v"(np), "v"(nx.f), "v"(nx.a) : "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" : : "v"(np), "v"(nx.f), "v"(nx.a), "v"(nx.c) : "memory");
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -195,14 +223,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         constexpr int NW9 = NINE ? 9 : 3;
         // w[k][slot]: NINE: coe1 .. coe9 (w[4] = coe5); else w[0] = AP, w[1] = CQ, w[2] = coe5.  y1: the optimistic body's
         // reciprocal, -0 where the point never updates; the exact body keeps 1 / 0 ("updates" / "idle") there instead.
-        f2 w[NW9][S], y1[S], ff[S];
+        using WT = std::conditional_t<MP, float, f2>;    // a row's weights: per chunk, or one for both members
+        const WT zeroW = WT{};
+        WT w[NW9][S], y1[S];
+        f2 ff[S];
         f2 hist[T][2];
-        f2 cq_prev = f2{0.f, 0.f}, by_prev = f2{0.f, 0.f};    // the row before the newest: its CQ and BY make the new row's weights
+        WT cq_prev = zeroW, by_prev = zeroW;              // the row before the newest: its CQ and BY make the new row's weights
 #pragma unroll
         for (int k = 0; k < S; ++k) {
-            y1[k] = ff[k] = f2{0.f, 0.f};
+            y1[k] = zeroW; ff[k] = f2{0.f, 0.f};
 #pragma unroll
-            for (int q = 0; q < NW9; ++q) w[q][k] = f2{0.f, 0.f};
+            for (int q = 0; q < NW9; ++q) w[q][k] = zeroW;
         }
 #pragma unroll
         for (int l = 0; l < T; ++l) hist[l][0] = hist[l][1] = f2{0.f, 0.f};
@@ -228,10 +259,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 const int rowa = ya + jr, rowb = yb + jr;
                 constexpr int slot = u % S, q = u & 1;
                 const f2 p0 = psr[u & 3], p1 = psr[(u + 3) & 3], p2 = psr[(u + 2) & 3];
-                const f2 fa = fac[u & 1].f, ap = fac[u & 1].a, cq = fac[u & 1].c;
+                const f2 fa = fac[u & 1].f;
+                WT ap, cq;
+                if constexpr (MP) { ap = fac[u & 1].a.x; cq = fac[u & 1].a.y; } else { ap = fac[u & 1].a; cq = fac[u & 1].c; }
                 f2& np = psr[(u + 1) & 3];                // where the next tick's row goes
                 Fac& nx = fac[(u + 1) & 1];
-                const f2 bx = f2{0.f, 0.f}, by = f2{0.f, 0.f};   // (b = 0: what the exact body's nine weights are made of besides AP, CQ)
+                const WT bx = zeroW, by = zeroW;              // (b = 0: what the exact body's nine weights are made of besides AP, CQ)
                 if constexpr (sub == 0) {
                     // a group starts: the slot of the group before it is free (its last row was read two ticks ago) and takes the
                     // group DG ahead; the next tick's row is this group's second, in LDS since this group's first was read
@@ -270,30 +303,33 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                             bad = bad || (__builtin_bit_cast(unsigned, up.x) & 0x7f800000u) == 0x7f800000u ||
                                   (__builtin_bit_cast(unsigned, up.y) & 0x7f800000u) == 0x7f800000u;
                         // the star of elliptic_tools.f90:77-85 in its order (terms 2, 4, 5, 6, 8); coe4 * psi(i-1) = (AP * psi)(i-1)
-                        const f2 Pm = w[0][sl] * oc;
-                        f2 Rv = w[1][sl] * up;
+                        const f2 wa = b2(w[0][sl]);
+                        const f2 Pm = wa * oc;
+                        f2 Rv = b2(w[1][sl]) * up;
                         Rv = f2{Rv.x + zshr1(Pm.x), Rv.y + zshr1(Pm.y)};
-                        Rv = Rv + w[2][sl] * oc;
-                        Rv = Rv + f2{w[0][sl].x * zshl1(oc.x), w[0][sl].y * zshl1(oc.y)};
-                        Rv = Rv + w[1][slm] * om;
+                        Rv = Rv + b2(w[2][sl]) * oc;
+                        Rv = Rv + f2{wa.x * zshl1(oc.x), wa.y * zshl1(oc.y)};
+                        Rv = Rv + b2(w[1][slm]) * om;
                         Rv = Rv - ff[sl];                 // :190
-                        up = oc + z_q2(Rv, w[2][sl], y1[sl]);   // :238 (alpha = 1; -d = coe5)
+                        up = oc + z_q2(Rv, b2(w[2][sl]), b2(y1[sl]));   // :238 (alpha = 1; -d = coe5)
                     } else {
                         // elliptic_tools.f90:77-85 left to right, :190, :238
-                        f2 Rv = f2{w[0][sl].x * zshr1(up.x), w[0][sl].y * zshr1(up.y)};
-                        Rv = Rv + w[1][sl] * up;
-                        Rv = Rv + f2{w[2][sl].x * zshl1(up.x), w[2][sl].y * zshl1(up.y)};
-                        Rv = Rv + f2{w[3][sl].x * zshr1(oc.x), w[3][sl].y * zshr1(oc.y)};
-                        Rv = Rv + w[4][sl] * oc;
-                        Rv = Rv + f2{w[5][sl].x * zshl1(oc.x), w[5][sl].y * zshl1(oc.y)};
-                        Rv = Rv + f2{w[6][sl].x * zshr1(om.x), w[6][sl].y * zshr1(om.y)};
-                        Rv = Rv + w[7][sl] * om;
-                        Rv = Rv + f2{w[8][sl].x * zshl1(om.x), w[8][sl].y * zshl1(om.y)};
+                        const f2 w0 = b2(w[0][sl]), w2 = b2(w[2][sl]), w3 = b2(w[3][sl]), w4 = b2(w[4][sl]), w5_ = b2(w[5][sl]),
+                                 w6 = b2(w[6][sl]), w8 = b2(w[8][sl]), yy = b2(y1[sl]);
+                        f2 Rv = f2{w0.x * zshr1(up.x), w0.y * zshr1(up.y)};
+                        Rv = Rv + b2(w[1][sl]) * up;
+                        Rv = Rv + f2{w2.x * zshl1(up.x), w2.y * zshl1(up.y)};
+                        Rv = Rv + f2{w3.x * zshr1(oc.x), w3.y * zshr1(oc.y)};
+                        Rv = Rv + w4 * oc;
+                        Rv = Rv + f2{w5_.x * zshl1(oc.x), w5_.y * zshl1(oc.y)};
+                        Rv = Rv + f2{w6.x * zshr1(om.x), w6.y * zshr1(om.y)};
+                        Rv = Rv + b2(w[7][sl]) * om;
+                        Rv = Rv + f2{w8.x * zshl1(om.x), w8.y * zshl1(om.y)};
                         Rv = Rv - ff[sl];
-                        if constexpr (!EXACT) up = oc + z_q2(Rv, w[4][sl], y1[sl]);
+                        if constexpr (!EXACT) up = oc + z_q2(Rv, w4, yy);
                         else {
-                            const f2 upd = f2{oc.x + Rv.x / (-w[4][sl].x), oc.y + Rv.y / (-w[4][sl].y)};
-                            up = f2{y1[sl].x != 0.0f ? upd.x : oc.x, y1[sl].y != 0.0f ? upd.y : oc.y};
+                            const f2 upd = f2{oc.x + Rv.x / (-w4.x), oc.y + Rv.y / (-w4.y)};
+                            up = f2{yy.x != 0.0f ? upd.x : oc.x, yy.y != 0.0f ? upd.y : oc.y};
                         }
                     }
                     (void)slm;
@@ -305,7 +341,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     const u4 v = *(const u4*)&obuf[sch][srow][4 * sgc];
                     const int r_ = (sch ? rowb : rowa) - T - 1 + srow;
                     const bool okr = r_ >= sy0 && r_ < sy1;
-                    const int off = r_ * pitch4 + scol4;
+                    const int off = r_ * pitch4 + scol4 + (sch ? dmo4 : 0);
                     __builtin_amdgcn_raw_buffer_store_b128(v, outr, (okr && s_full) ? off : (int)0x80000000, 0, 0);
                     if (nvalid & 3) {                     // (the last strip only) the columns of a partial four, one by one
 #pragma unroll
@@ -319,8 +355,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 }
                 // ---- the new row's weights take a free slot
                 const bool ia = col_int && rowa >= 1 && rowa <= g.ny - 2, ib = col_int && rowb >= 1 && rowb <= g.ny - 2;
-                const f2 am = zshr2(ap);
-                f2 c5;
+                const WT am = zshrW(ap);
+                WT c5;
                 if constexpr (!NINE) {
                     c5 = -(am + ap + cq_prev + cq);       // elliptic_tools.f90:50, left to right
                     w[0][slot] = ap;
@@ -328,7 +364,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     w[2][slot] = c5;
                 } else {
                     // elliptic_tools.f90:46-54 with b = 0, every term kept so that the zeros' signs are the reference's (as exact_tile, xee_sweepq.hip)
-                    const f2 bxm = zshr2(bx), bym = by_prev, cm = cq_prev;
+                    const WT bxm = zshrW(bx), bym = by_prev, cm = cq_prev;
                     c5 = -(am + ap + cm + cq);
                     w[0][slot] = -(bxm + by);
                     w[1][slot] = cq + (bx - bxm);
@@ -341,8 +377,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     w[8][slot] = -(bx + bym);
                 }
                 cq_prev = cq; by_prev = by;
-                if constexpr (EXACT) y1[slot] = f2{ia ? 1.0f : 0.0f, ib ? 1.0f : 0.0f};
-                else y1[slot] = f2{ia ? quotient_y1(-c5.x) : -0.0f, ib ? quotient_y1(-c5.y) : -0.0f};
+                if constexpr (MP) {                       // (the two halves are the same points of two members: ia = ib)
+                    if constexpr (EXACT) y1[slot] = ia ? 1.0f : 0.0f;
+                    else y1[slot] = ia ? quotient_y1(-c5) : -0.0f;
+                    (void)ib;
+                } else {
+                    if constexpr (EXACT) y1[slot] = f2{ia ? 1.0f : 0.0f, ib ? 1.0f : 0.0f};
+                    else y1[slot] = f2{ia ? quotient_y1(-c5.x) : -0.0f, ib ? quotient_y1(-c5.y) : -0.0f};
+                }
                 ff[slot] = fa;
                 if constexpr (!EXACT) lds_wait(np, nx);   // the next tick's row has arrived (LDS returns in order)
         };
@@ -448,12 +490,16 @@ void launch_sweep_z(const Grid& g, const float* psi_in, float* psi_out, const fl
     constexpr int W = 64 - 2 * 6;
     const int nstrip = (g.nx - 2 + W - 1) / W;
     const int Lc = (g.ny - 2 + 2 * P - 1) / (2 * P);
-    const long long units = (long long)nstrip * P * g.members;
-    if (desc) { desc->name = "k_sweep_z<star>"; desc->T = T; desc->tile_w = 64; desc->tile_h = Lc; desc->tiles = units; desc->streamed = true; }
+    // members in pairs where they all share AP and CQ (and the spans of the paired descriptors stay below 2^31 bytes)
+    const size_t ks = g.kstride ? g.kstride : (size_t)g.members * g.plane;
+    const bool pairs = (g.base_shared & 3) == 3 && g.members >= 2 && (ks + g.plane) * 4 + 64 < ((size_t)1 << 31);
+    const long long units = pairs ? (long long)nstrip * 2 * P * ((g.members + 1) / 2) : (long long)nstrip * P * g.members;
+    if (desc) { desc->name = pairs ? "k_sweep_z<star, member pairs>" : "k_sweep_z<star>"; desc->T = T; desc->tile_w = 64; desc->tile_h = Lc; desc->tiles = units; desc->streamed = true; }
     // (T = 8 was measured too: 17.3 against 17.6 us per iteration at equal P -- what it saves in bytes it pays in halo and run-in,
     // and its 22 strips leave no P that fills the 2048 places; profiles/r03/z_ablation.txt)
-    hipLaunchKernelGGL((k_sweep_z<6>), dim3((unsigned)(8 * ((units + 7) / 8))), dim3(64), 0, s, g, psi_in, psi_out, base, f, st, nstrip, P, Lc,
-                       (int)units, exact_only, diag);
+    const dim3 grid((unsigned)(8 * ((units + 7) / 8)));
+    if (pairs) hipLaunchKernelGGL((k_sweep_z<6, true>), grid, dim3(64), 0, s, g, psi_in, psi_out, base, f, st, nstrip, P, Lc, (int)units, exact_only, diag);
+    else hipLaunchKernelGGL((k_sweep_z<6, false>), grid, dim3(64), 0, s, g, psi_in, psi_out, base, f, st, nstrip, P, Lc, (int)units, exact_only, diag);
 }
 
 }  // namespace xee
