@@ -7,19 +7,23 @@
 // two ticks and this one produced), and level T of row j - T leaves for memory.  No barrier; no halo in z except the T
 // rows of run-in at the two ends of a chunk of rows; the halo in r stays (lane shifts).  Two chunks of the same strip are
 // walked at once, one in each half of a packed register pair, so the arithmetic is the packed fp32 of k_sweep_q.
-// 35 % fewer instructions per iteration than k_sweep_q (4.6 M against 7.0 M wave instructions for 32 cases of 1024x512).
+// 37 % fewer instructions per iteration than k_sweep_q (4.4 M against 7.0 M wave instructions for 32 cases of 1024x512).
 //
 // Memory: ten dword accesses per tick cost a third of the walk, and so do 2.5 wide ones -- the cost follows the bytes
-// (ablations: profiles/r03/z_ablation.txt).  A fetch moves two rows of a plane for both chunks per instruction -- LDS-DMA of
-// 16 bytes per lane, which lands as [chunk][row][64 columns] in LDS without passing a register -- two groups ahead of the
-// walk, and the results of two ticks go through LDS into one 16-byte store: 2.5 memory instructions per tick.  14 KB of LDS
-// per wave, one wave per workgroup, at most two per SIMD (amdgpu_waves_per_eu): a launch of up to 2048 waves spreads over
-// all 256 CUs whatever order the dispatcher takes them in (four-wave workgroups, four waves per SIMD allowed, were packed
-// four to a CU while other CUs idled: 14.3 us per iteration with or without their memory operations).
+// (ablations: profiles/r03/z_ablation.txt).  A fetch moves two rows of a plane for both halves per instruction -- LDS-DMA of
+// 16 bytes per lane, which lands as [plane][half][row][64 columns] in LDS without passing a register -- three groups (member
+// pairs: four) ahead of the one being read; the next tick's row is read from LDS a tick ahead; the results of two ticks go through
+// LDS into one 16-byte store: 2.5 memory instructions per tick.  17 KB of LDS per wave (member pairs: 16), one wave per
+// workgroup, at most two per SIMD (amdgpu_waves_per_eu): a launch of up to 2048 waves spreads over all 256 CUs whatever order
+// the dispatcher takes them in (four-wave workgroups, four waves per SIMD allowed, were packed four to a CU while other CUs
+// idled: 14.3 us per iteration with or without their memory operations).
 //
-// With T = 6 the walk is bound by HBM: 20 bytes per point and launch (psi, f, AP, CQ in, psi out), 4.9 TB/s measured with the
-// arithmetic taken out.  A larger T trades that for run-in and halo (T = 8: 48 own columns of 64, and 22 strips x 3 chunk
-// pairs x 32 cases = 2112 waves do not fit the 2048 places); DESIGN.md "The streaming sweep" has the numbers.
+// Where every member has its own operator the walk is bound by HBM at T = 6: 20 bytes per point and launch (psi, f, AP, CQ in,
+// psi out), 4.9 TB/s measured with the arithmetic taken out.  A larger T trades that for run-in and halo (T = 8: 48 own columns
+// of 64, and 22 strips x 3 chunk pairs x 32 cases = 2112 waves do not fit the 2048 places).  Members that share their operator
+// read ONE copy of AP and CQ (Grid.base_shared; 12.5 bytes per point and launch for 16 members) and are walked in pairs (MP,
+// below): the VALU then bounds the walk (10.4 us per iteration of 32 cases with the memory operations removed, 11 - 12 with
+// them).  DESIGN.md "The streaming sweep" has the numbers.
 //
 // BAROTROPIC operator (five-point star from the two generating planes AP, CQ), alpha = 1, plain launches (no residual
 // plane): the host (xee_api.hip) gives the residual-writing launch at the end of a check block and any remainder to
@@ -30,7 +34,8 @@
 //     |R - f| above the lower bound by construction -- xee_sweepq.hip "Zero residuals"); the upper bound only guards
 //     against an overflow inside the quotient, and an overflow there ends as a NaN or an infinity in the point's own result,
 //     which the wave looks for in what it stores (and in what enters its last level: see there);
-//   * points that never update (rim, rows and columns outside the domain -- clamped copies) are kept idle by y1 = -0 alone:
+//   * points that never update (the rim; rows outside the domain -- clamped copies; lanes right of it -- whatever follows the row
+//     in memory) are kept idle by y1 = -0 alone:
 //     their quotient is a zero whatever their "residual", and psi + (+-0) = psi unless psi is -0;
 //   * a wave that loaded a -0 or stored a non-finite value walks its chunks again with the exact body: the reference's
 //     nine-term sum in its order, the IEEE division, idle points by selection -- k_sweep_q's exact_tile, streamed.
@@ -103,8 +108,8 @@ __device__ __forceinline__ void z_for(F&& body) { z_for_impl(body, std::make_int
 // interior rows [1 + c Lc, 1 + (c + 1) Lc), clipped to ny - 2, and is walked from T rows before its first to T rows past its
 // last so that level T of its own rows is complete.
 // Fetch groups of TWO rows: one 16-byte LDS-DMA instruction per plane and group -- lanes 0..31 carry rows r, r + 1 of chunk a,
-// lanes 32..63 those of chunk b (16 lanes x 16 bytes = the 64 columns of a row) -- landing as [chunk][row][64] in LDS, two
-// groups ahead of the walk.  (Groups of four rows, one group ahead, 20 KB: the same speed.)
+// lanes 32..63 those of chunk b (16 lanes x 16 bytes = the 64 columns of a row) -- landing as [chunk][row][64] in LDS.
+// (Groups of four rows, one group ahead, 20 KB: the same speed.)
 // MP ("member pairs"; the launcher chooses it where all members share AP and CQ): the two halves of the register pair are the SAME
 // chunk of TWO members instead of two chunks of one -- the weights of a row (AP, CQ, coe5, y1) then are one value for both halves:
 // half the registers and half the arithmetic to make them, three fetches per group instead of four (AP and CQ share one: lanes
