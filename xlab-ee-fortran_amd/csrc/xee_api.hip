@@ -303,9 +303,11 @@ int z_decide(xee_ensemble* e, float alpha, int tb_T, int streams, int members)
     const int k = e->opts.kernel;
     if (!(e->have_base && e->base_baro && alpha == 1.0f && (k == 0 || k == 4) && tb_T >= sweep_z_T())) return XEE_OK;
     if (e->g.plane * sizeof(float) >= ((size_t)1 << 31) - 64) return XEE_OK;       // (byte offsets inside a plane are 32-bit)
-    // (78: measured end to end, tools/auto_vs_tiled.py -- at 73..75 the streamed solve is level with the tiled one or, for one
-    // 4096x2048 case, 8 % behind it; at 79..82 it is 10 % ahead)
-    int P = sweep_z_pairs(e->g, members, streams, k == 4 ? 0 : 78);
+    // (measured end to end, tools/auto_vs_tiled.py, profiles/r03/auto_vs_tiled.txt.  Members that each read their own operator planes:
+    // at 73 .. 75 the streamed solve is level with the tiled one or, for one 4096x2048 case, 4 - 8 % behind it, at 79 .. 82 it is
+    // 10 % ahead: 78.  Members that share AP and CQ (one copy, walked in pairs): 8 - 13 % ahead at 73 already, 20 % behind at 41: 70.)
+    const bool shared = (e->g.base_shared & 3) == 3 && members >= 2;
+    int P = sweep_z_pairs(e->g, members, streams, k == 4 ? 0 : (shared ? 70 : 78));
     if (P > 0 && e->opts.z_pairs > 0) P = e->opts.z_pairs;
     if (P <= 0) return XEE_OK;
     if (!e->zstat) HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->zstat), 3 * sizeof(unsigned) * e->g.members));

@@ -468,8 +468,8 @@ int sweep_z_T() { return 6; }
 // The device holds 2048 waves of this kernel (eight per CU); a launch of n waves takes ceil(n / places) rounds, and a
 // chunk of Lc rows costs Lc + 2 T ticks: the P in 1 .. (ny - 2) / 64 with the largest product of the rounds' filling
 // and Lc / (Lc + 2 T).  Returns 0 where that product is below `min_eff_percent`: k_sweep_q's tiles use the device better
-// there (the caller's threshold is measured end to end: 32 cases of 1024x512 reach 82 and gain 10 - 14 %, 24 cases 79 and
-// gain 10 %, 16 cases 73 and gain 4 %, one case of 4096x2048 75 and loses 8 %; profiles/r03/auto_vs_tiled.txt).
+// there (the caller's thresholds are measured end to end, profiles/r03/auto_vs_tiled.txt: 32 cases of 1024x512 reach 82, 24 cases 79,
+// 16 cases and 4 cases of 2048x1024 73, one case of 4096x2048 75, 8 cases of 1024x512 41).
 int sweep_z_pairs(const Grid& g, int members, int streams, int min_eff_percent)
 {
     constexpr int T = 6, W = 64 - 2 * T;
