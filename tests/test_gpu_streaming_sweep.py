@@ -84,22 +84,22 @@ def test_streamed_sweep_against_the_oracle():
 
 
 def test_check_block_plan():
-    """A block of `check_step` iterations: k_sweep_z's launches of six, then k_sweep_q's residual-writing launch, which takes
-    the remainder along (tb_T .. tb_T + 5 iterations).  A last block without a check: the remainder first, never a single
-    iteration."""
+    """A block of `check_step` iterations: k_sweep_z's launches of six and, where the length is a multiple of six or four more,
+    its own residual-writing launch of six or four; else k_sweep_q's residual-writing launch, which takes the remainder along
+    (tb_T .. tb_T + 5 iterations).  A last block without a check: the remainder first, never a single iteration."""
     nr, nz = 120, 90
     A, B, Cc, bc = H.member_inputs(nr, nz, 1)
     f = _forcing(A)
     for check_step, n, tb_T, want_z, want_all in (
-            (100, 300, 8, 3 * 15, 3 * 16),        # 15 x 6 + 10
-            (100, 250, 8, 2 * 15 + 8, 2 * 16 + 9),   # ... and a last block of 50 without a check: 2 + 8 x 6
-            (100, 207, 8, 2 * 15, 2 * 16 + 1),    # ... of 7: one launch (a remainder of one takes a launch of six with it)
-            (99, 198, 8, 2 * 15, 2 * 16),         # 15 x 6 + 9
+            (100, 300, 8, 3 * 17, 3 * 17),        # 16 x 6 + 4, the last by k_sweep_z too
+            (100, 250, 8, 2 * 17 + 8, 2 * 17 + 9),   # ... and a last block of 50 without a check: 2 + 8 x 6
+            (100, 207, 8, 2 * 17, 2 * 17 + 1),    # ... of 7: one launch (a remainder of one takes a launch of six with it)
+            (99, 198, 8, 2 * 15, 2 * 16),         # 15 x 6 + 9: the residual-writing launch is k_sweep_q's
             (50, 100, 8, 2 * 7, 2 * 8),           # 7 x 6 + 8
             (20, 40, 8, 2 * 2, 2 * 3),            # 2 x 6 + 8
             (13, 26, 8, 0, 2 * 2),                # 5 + 8: no room for a launch of six
-            (40, 80, 6, 2 * 5, 2 * 6),            # tb_T = 6: 5 x 6 + 10
-            (30, 60, 16, 2 * 3, 2 * 4)):          # tb_T = 16: 2 x 6 + 18 is too long a last launch: 3 x 6 + 12
+            (40, 80, 6, 2 * 7, 2 * 7),            # 6 x 6 + 4
+            (30, 60, 16, 2 * 5, 2 * 5)):          # 5 x 6
         ref, rr, _, _ = _run(A, B, Cc, bc, f, n, {"kernel": 3, "tb_T": tb_T}, check_step=check_step)
         got, rg, t, _ = _run(A, B, Cc, bc, f, n, {"kernel": 4, "tb_T": tb_T}, check_step=check_step)
         assert (t["z_launches"], t["sweep_launches"]) == (want_z, want_all), (check_step, n, tb_T, t)
@@ -211,7 +211,7 @@ def test_a_large_batch_streams_by_itself_and_matches_the_reference_files():
             rec = e.solve(n, 1e-8, -1.0, 1.0)
             outs[k] = (e.download("PSI"), rec, e.timing())
     t = outs[0][2]
-    assert t["sweep_streams"] == 2 and t["z_launches"] == 2 * 2 * 15 and t["sweep_launches"] == 2 * 2 * 16, t
+    assert t["sweep_streams"] == 2 and t["z_launches"] == 2 * 2 * 17 and t["sweep_launches"] == 2 * 2 * 17, t
     assert outs[3][2]["z_launches"] == 0
     assert biteq(outs[0][0], outs[3][0]) and outs[0][1]["err_now"].tobytes() == outs[3][1]["err_now"].tobytes()
     assert t["inline_redo_tiles"] == 0 and t["redo_tiles"] == 0
@@ -261,5 +261,38 @@ def test_streamed_launches_inside_block_graphs():
     f = _forcing(A)
     want, rw, tw, _ = _run(A, B, Cc, bc, f, n, {"kernel": 3}, r1=1e-30)
     got, rg, tg, _ = _run(A, B, Cc, bc, f, n, {"kernel": 4}, r1=1e-30)
-    assert tg["z_launches"] == 70 * 15 and tg["sweep_launches"] == 70 * 16 and tg["iterations"] == n
+    assert tg["z_launches"] == 70 * 17 and tg["sweep_launches"] == 70 * 17 and tg["iterations"] == n
     assert biteq(got, want) and rg["err_now"].tobytes() == rw["err_now"].tobytes() and rg["iters"].tolist() == rw["iters"].tolist()
+
+
+@pytest.mark.parametrize("members", [1, 3, 4])
+def test_streamed_residual_writing_launch(members):
+    """A check block whose length is 16 x 6 + 4 (the default 100) or a multiple of six ends in k_sweep_z's own residual-writing
+    launch (4 or 6 iterations): the residual plane, bit for bit, and the iterate against k_sweep_q's; every launch streamed.  With
+    several members (sharing their operator: member pairs) one of which has converged and stopped, nothing of the stopped one is
+    written by the later blocks."""
+    nr, nz = 140, 95
+    A, B, Cc, bc = H.rich_inputs(nr, nz, seed=31)
+    outs = {}
+    for cs, n in ((100, 300), (60, 180), (22, 66), (50, 150)):
+        for k in (3, 4):
+            with xee.Ensemble(nr, nz, members) as e:
+                e.set_option("kernel", k)
+                e.set_profiles(xee.profiles(nr, nz))
+                for m in range(members):
+                    f = _forcing(A, seed=m) * np.float32(1e3 if m == 1 else 1.0)
+                    for name, arr in (("A", A), ("B", B), ("C", Cc), ("BC_INIT", bc * np.float32(1 + m)), ("FORCING", f)):
+                        e.upload(name, arr, first=m)
+                e.assemble(0)
+                # (member 0's residual falls below r1 at the first check of the longer blocks: converge_time = 1 stops it there)
+                rec = e.solve(n, 3e-7, -1.0, 1.0, check_step=cs, converge_time=1)
+                outs[k] = (e.download("PSI"), e.download("RESIDUAL"), rec, e.timing())
+        (pz, rz, recz, tz), (pq, rq, recq, tq) = outs[4], outs[3]
+        assert recz["iters"].tolist() == recq["iters"].tolist() and recz["err_now"].tobytes() == recq["err_now"].tobytes(), (cs, recz["iters"], recq["iters"])
+        assert biteq(pz, pq), cs
+        assert biteq(rz[:, 1:-1, 1:-1], rq[:, 1:-1, 1:-1]), cs
+        blocks = int(max(recz["iters"])) // cs
+        if cs in (100, 60, 22):          # 16 x 6 + 4, 10 x 6, 3 x 6 + 4: all of them k_sweep_z's
+            assert tz["z_launches"] == tz["sweep_launches"] > 0, (cs, tz)
+        else:                            # 50 = 7 x 6 + 8: the residual-writing launch is k_sweep_q's
+            assert 0 < tz["z_launches"] == tz["sweep_launches"] - blocks, (cs, tz)

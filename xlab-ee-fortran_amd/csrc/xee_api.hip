@@ -333,6 +333,13 @@ void plan_block(int total, bool to_check, int tb_T, int zT, std::vector<int>* pl
 {
     plan->clear();
     if (zT > 0 && tb_T > 1 && total >= (to_check ? tb_T : 0) + zT) {
+        if (to_check && (total % zT == 0 || total % zT == 4)) {
+            // k_sweep_z writes the residual too, after 6 or 4 iterations: the whole block is its (100 = 16 x 6 + 4)
+            const int wr = total % zT == 0 ? zT : 4;
+            for (int i = 0; i < (total - wr) / zT; ++i) plan->push_back(zT);
+            plan->push_back(wr);
+            return;
+        }
         if (to_check) {
             int nz = (total - tb_T) / zT;
             int wr = total - nz * zT;                     // tb_T .. tb_T + zT - 1
@@ -368,9 +375,10 @@ bool launch_blocked(xee_ensemble* e, const float* psi_in, float* psi_out, float*
 {
     const int k = e->opts.kernel;
     if (!st) st = e->st;
-    if (e->z_pairs_now > 0 && !res && T == sweep_z_T() && alpha == 1.0f) {
-        launch_sweep_z(e->g, psi_in, psi_out, e->base, e->f, st, T, e->z_pairs_now, e->opts.q_exact_only, e->redo, &e->last_sweep, e->stream);
-        return false;
+    if (e->z_pairs_now > 0 && alpha == 1.0f && sweep_z_can(T, res != nullptr)) {
+        launch_sweep_z(e->g, psi_in, psi_out, e->base, e->f, res, res ? snap : nullptr, st, T, e->z_pairs_now, e->opts.q_exact_only, e->redo,
+                       &e->last_sweep, e->stream);
+        return res != nullptr && snap != nullptr;           // (the residual-writing form also wrote the snapshot)
     }
     if (e->have_base && k != 1) {
         if (k == 2) launch_sweep_tb4(e->g, psi_in, psi_out, e->base, e->f, res, st, alpha, T, e->base_baro, e->opts, &e->last_sweep, e->stream);
@@ -976,7 +984,7 @@ int solve_pipelined(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float 
         for (size_t i = 0; i < plan.size(); ++i) {
             const int n = plan[i];
             const bool check = to_check && i + 1 == plan.size();
-            const bool will_stream = e->z_pairs_now > 0 && !check && n == sweep_z_T() && alpha == 1.0f;
+            const bool will_stream = e->z_pairs_now > 0 && alpha == 1.0f && sweep_z_can(n, check);
             if (time_z && will_stream && !z_open) { hipEventRecord(e->evZ[sl][0], s); z_open = true; }
             if (z_open && !will_stream) { hipEventRecord(e->evZ[sl][1], s); z_open = false; }
             e->last_sweep.tiles = 0; e->last_sweep.streamed = false;

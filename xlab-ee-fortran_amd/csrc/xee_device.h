@@ -151,8 +151,11 @@ int  sweep_z_T();                                         // iterations per laun
 int  sweep_z_pairs(const Grid& g, int members, int streams, int min_eff_percent);   // chunk pairs per strip, 0 = "use k_sweep_q"
 void launch_z_extremes(const Grid& g, const float* base, const float* f, unsigned* zstat /* device, 3 per member */, hipStream_t s);
 bool z_member_ok(const unsigned* zstat3 /* host copy of one member's three words */);
+bool sweep_z_can(int T, bool with_residual);            // 6 iterations plain; 6 or 4 with the residual of the last one
 void launch_sweep_z(const Grid& g, const float* psi_in, float* psi_out, const float* base, const float* f,
-                    const MemberState* st, int T /* = sweep_z_T() */, int chunk_pairs, int exact_only,
+                    float* res /* nullptr, or the residual plane of the launch's last iteration ... */,
+                    float* snap /* ... and (or nullptr) a second copy of the new iterate's interior, active members only */,
+                    const MemberState* st, int T, int chunk_pairs, int exact_only,
                     int* diag /* device, 2 ints or nullptr: [1] counts the waves that fell back to the exact body */,
                     SweepDesc* desc, hipStream_t s);
 int  tb_max_T();

@@ -114,15 +114,18 @@ __device__ __forceinline__ void z_for(F&& body) { z_for_impl(body, std::make_int
 // chunk of TWO members instead of two chunks of one -- the weights of a row (AP, CQ, coe5, y1) then are one value for both halves:
 // half the registers and half the arithmetic to make them, three fetches per group instead of four (AP and CQ share one: lanes
 // 0..31 AP's two rows, lanes 32..63 CQ's), 3 KB of LDS per group and so one more group in flight.
-template <int T, bool MP>
+// WR: the launch at the end of a check block -- the residual of its LAST iteration (do_elliptic(psi) - f, elliptic_tools.f90:189-190)
+// goes to `res` and a second copy of the new iterate to `snap` (may be null), for the members that are active (a stopped member's
+// snapshot is its result: nothing of it may be written).
+template <int T, bool MP, bool WR>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sweep_z(Grid g, const float* __restrict__ psi_in, float* __restrict__ psi_out,
         const float* __restrict__ base, const float* __restrict__ f, const MemberState* __restrict__ st, int nstrip, int P, int Lc, int nunits,
-        int exact_only, int* __restrict__ diag)
+        int exact_only, int* __restrict__ diag, float* __restrict__ res, float* __restrict__ snap)
 {
     // rows whose weights are in flight: j - T .. j, and a spare slot so that one turn of the unrolled loop (the slots' rotation
     // x the two-row groups and the history's parity) is S ticks
     constexpr int S = (T + 2) & ~1;
-    constexpr int U = S;
+    constexpr int U = (S % 4 == 0) ? S : 2 * S;           // (... and of the four places the psi rows rotate through)
     constexpr int W = 64 - 2 * T;
     static_assert(W % 4 == 0 && U % 2 == 0 && U % S == 0, "the 16-byte stores take the strip's own columns in fours");
     constexpr int NF = MP ? 3 : 4;                        // fetch instructions per group: psi, f, AP, CQ (MP: AP and CQ in one)
@@ -130,6 +133,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     constexpr int NG = DG + 1;                            // groups in LDS
     __shared__ __attribute__((aligned(16))) float ring[NG][NF][2][2][64];   // [group][plane][chunk or member][row][column]: 4 KB (MP: 3 KB) per group
     __shared__ __attribute__((aligned(16))) float obuf[2][2][64];
+    __shared__ __attribute__((aligned(16))) float robuf[WR ? 2 : 1][2][64];   // (WR) the residual rows, as obuf
     const int lane = threadIdx.x;
     const int part = (int)gridDim.x >> 3;                 // (the grid is a multiple of eight: workgroup b runs on XCD b % 8)
     const int wv = ((int)blockIdx.x & 7) * part + ((int)blockIdx.x >> 3);
@@ -138,7 +142,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int per_member = nstrip * (MP ? 2 * P : P);
     const int mu = wv / per_member;
     const int m = MP ? 2 * mu : mu, mb = MP ? (m + 1 < g.members ? m + 1 : m) : m;
-    if (st && !st[m].active && !st[mb].active) return;  // (MP: a stopped member beside a running one is iterated on: its result is its snapshot's)
+    const bool act_a = !st || st[m].active, act_b = !st || st[mb].active;
+    if (!act_a && !act_b) return;                         // (MP: a stopped member beside a running one is iterated on: its result is its snapshot's)
     const int rem = wv - mu * per_member;
     const int s = rem % nstrip, c = rem / nstrip;
     const int lo = s == 0 ? 1 : T;
@@ -154,6 +159,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const rsrc_t pr = zrsrc(psi_in + mo, g, 16 + dmo4), fr = zrsrc(f + mo, g, 16 + dmo4);
     const rsrc_t apr = zrsrc(base + ((g.base_shared & 1) ? 0 : mo), g, 16 + dcq4), cqr = zrsrc(base + ks + ((g.base_shared & 2) ? 0 : mo), g, 16);
     const rsrc_t outr = zrsrc(psi_out + mo, g, dmo4);
+    const rsrc_t resr = zrsrc((WR ? res : psi_out) + mo, g, dmo4), snapr = zrsrc((WR && snap ? snap : psi_out) + mo, g, dmo4);
     const int ya = 1 + c * Lc, yb = MP ? ya : 1 + (c + P) * Lc;
     const int yend_a = ya + Lc < g.ny - 1 ? ya + Lc : g.ny - 1, yend_b = yb + Lc < g.ny - 1 ? yb + Lc : g.ny - 1;
     const int pitch4 = g.pitch * 4;
@@ -289,6 +295,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 if constexpr (!EXACT)
                     bad = bad || __builtin_bit_cast(unsigned, p0.x) == 0x80000000u || __builtin_bit_cast(unsigned, p0.y) == 0x80000000u;
                 f2 up = p0;
+                f2 rlast = f2{0.f, 0.f};                  // (WR) the residual of the last level's row
                 z_for<T>([&](auto tc) {
                     constexpr int t = decltype(tc)::value + 1;
                     constexpr int sl = ((u - t) % S + S) % S;
@@ -316,6 +323,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                         Rv = Rv + f2{wa.x * zshl1(oc.x), wa.y * zshl1(oc.y)};
                         Rv = Rv + b2(w[1][slm]) * om;
                         Rv = Rv - ff[sl];                 // :190
+                        if constexpr (WR && t == T) rlast = Rv;
                         up = oc + z_q2(Rv, b2(w[2][sl]), b2(y1[sl]));   // :238 (alpha = 1; -d = coe5)
                     } else {
                         // elliptic_tools.f90:77-85 left to right, :190, :238
@@ -331,6 +339,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                         Rv = Rv + b2(w[7][sl]) * om;
                         Rv = Rv + f2{w8.x * zshl1(om.x), w8.y * zshl1(om.y)};
                         Rv = Rv - ff[sl];
+                        if constexpr (WR && t == T) rlast = Rv;
                         if constexpr (!EXACT) up = oc + z_q2(Rv, w4, yy);
                         else {
                             const f2 upd = f2{oc.x + Rv.x / (-w4.x), oc.y + Rv.y / (-w4.y)};
@@ -342,16 +351,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 // ---- level T of row jr - T: into the group of two result rows; the second sends the group to memory
                 obuf[0][sub][o_w] = up.x;
                 obuf[1][sub][o_w] = up.y;
+                if constexpr (WR) { robuf[0][sub][o_w] = rlast.x; robuf[1][sub][o_w] = rlast.y; }
                 if constexpr (sub == 1) {
                     const u4 v = *(const u4*)&obuf[sch][srow][4 * sgc];
                     const int r_ = (sch ? rowb : rowa) - T - 1 + srow;
-                    const bool okr = r_ >= sy0 && r_ < sy1;
+                    // (WR: nothing of a stopped member is written, as k_sweep_q's residual-writing launch skips it)
+                    const bool okr = r_ >= sy0 && r_ < sy1 && (!WR || (sch ? act_b : act_a));
                     const int off = r_ * pitch4 + scol4 + (sch ? dmo4 : 0);
                     __builtin_amdgcn_raw_buffer_store_b128(v, outr, (okr && s_full) ? off : (int)0x80000000, 0, 0);
                     if (nvalid & 3) {                     // (the last strip only) the columns of a partial four, one by one
 #pragma unroll
                         for (int k = 0; k < 3; ++k)
                             __builtin_amdgcn_raw_buffer_store_b32(v[k], outr, (okr && k < s_part) ? off + 4 * k : (int)0x80000000, 0, 0);
+                    }
+                    if constexpr (WR) {
+                        const u4 vr = *(const u4*)&robuf[sch][srow][4 * sgc];
+                        __builtin_amdgcn_raw_buffer_store_b128(vr, resr, (okr && s_full) ? off : (int)0x80000000, 0, 0);
+                        if (snap) __builtin_amdgcn_raw_buffer_store_b128(v, snapr, (okr && s_full) ? off : (int)0x80000000, 0, 0);
+                        if (nvalid & 3) {
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) {
+                                __builtin_amdgcn_raw_buffer_store_b32(vr[k], resr, (okr && k < s_part) ? off + 4 * k : (int)0x80000000, 0, 0);
+                                if (snap) __builtin_amdgcn_raw_buffer_store_b32(v[k], snapr, (okr && k < s_part) ? off + 4 * k : (int)0x80000000, 0, 0);
+                            }
+                        }
                     }
                     if constexpr (!EXACT) {
 #pragma unroll
@@ -489,10 +512,12 @@ int sweep_z_pairs(const Grid& g, int members, int streams, int min_eff_percent)
     return best_eff * 100.0 >= (double)min_eff_percent ? best : 0;
 }
 
-void launch_sweep_z(const Grid& g, const float* psi_in, float* psi_out, const float* base, const float* f,
+bool sweep_z_can(int T, bool with_residual) { return T == 6 || (with_residual && T == 4); }
+
+void launch_sweep_z(const Grid& g, const float* psi_in, float* psi_out, const float* base, const float* f, float* res, float* snap,
                     const MemberState* st, int T, int P, int exact_only, int* diag, SweepDesc* desc, hipStream_t s)
 {
-    constexpr int W = 64 - 2 * 6;
+    const int W = 64 - 2 * T;
     const int nstrip = (g.nx - 2 + W - 1) / W;
     const int Lc = (g.ny - 2 + 2 * P - 1) / (2 * P);
     // members in pairs where they all share AP and CQ (and the spans of the paired descriptors stay below 2^31 bytes)
@@ -503,8 +528,11 @@ void launch_sweep_z(const Grid& g, const float* psi_in, float* psi_out, const fl
     // (T = 8 was measured too: 17.3 against 17.6 us per iteration at equal P -- what it saves in bytes it pays in halo and run-in,
     // and its 22 strips leave no P that fills the 2048 places; profiles/r03/z_ablation.txt)
     const dim3 grid((unsigned)(8 * ((units + 7) / 8)));
-    if (pairs) hipLaunchKernelGGL((k_sweep_z<6, true>), grid, dim3(64), 0, s, g, psi_in, psi_out, base, f, st, nstrip, P, Lc, (int)units, exact_only, diag);
-    else hipLaunchKernelGGL((k_sweep_z<6, false>), grid, dim3(64), 0, s, g, psi_in, psi_out, base, f, st, nstrip, P, Lc, (int)units, exact_only, diag);
+#define XEE_Z_LAUNCH(TT, MPAIR, WRES) hipLaunchKernelGGL((k_sweep_z<TT, MPAIR, WRES>), grid, dim3(64), 0, s, g, psi_in, psi_out, base, f, st, nstrip, P, Lc, (int)units, exact_only, diag, res, snap)
+    if (!res) { if (pairs) XEE_Z_LAUNCH(6, true, false); else XEE_Z_LAUNCH(6, false, false); }
+    else if (T == 4) { if (pairs) XEE_Z_LAUNCH(4, true, true); else XEE_Z_LAUNCH(4, false, true); }
+    else { if (pairs) XEE_Z_LAUNCH(6, true, true); else XEE_Z_LAUNCH(6, false, true); }
+#undef XEE_Z_LAUNCH
 }
 
 }  // namespace xee
