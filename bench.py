@@ -330,9 +330,13 @@ def main():
         if streamed:
             kernel, tb_T = "k_sweep_z", 6
             avg_launch_s = z_ms * 1e-3 / max(z_timed / streams, 1)
-            kernel_label = (f"k_sweep_z<star> (damped-Jacobi sweep streamed along z, 6 iterations per launch: {z_launches} of the "
-                            f"{launches} sweep launches; the others -- each check block's residual-writing launch and a remainder "
-                            f"-- are {info['name']}'s)")
+            if z_launches == launches:
+                kernel_label = (f"{info['name']} (damped-Jacobi sweep streamed along z: all {launches} sweep launches -- per check block of 100 "
+                                f"iterations 16 launches of 6 and one of 4 that also writes the residual)")
+            else:
+                kernel_label = (f"k_sweep_z<star> (damped-Jacobi sweep streamed along z, 6 iterations per launch: {z_launches} of the "
+                                f"{launches} sweep launches; the others -- each check block's residual-writing launch and a remainder "
+                                f"-- are k_sweep_q's)")
         ent = traffic_entry(kernel, nr, nz, members_per_launch, operator)
         # the committed counters are quoted only when they were taken on exactly this build of the kernel and driver
         here = current_build_hash()
