@@ -150,6 +150,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int x0 = s * W + 1 - lo;                        // column of lane 0
     const int gx = x0 + lane;
     const bool col_int = gx >= 1 && gx <= g.nx - 2;
+    const unsigned cmask = ~(unsigned)(((gx - 1) | (g.nx - 2 - gx)) >> 31);   // all ones where the column is interior (see `pick` below)
     const int nvalid = (g.nx - 2 - s * W) < W ? (g.nx - 2 - s * W) : W;
     const size_t mo = (size_t)m * g.plane, ks = g.kstride ? g.kstride : (size_t)g.members * g.plane;
     // (generating planes that all members share are read from member 0's copy: Grid.base_shared)
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int fhalf = lane >= 32 ? dmo4 : 0, fac4 = lane >= 32 ? dcq4 : 0;   // MP: the second half's member / CQ behind AP
     auto fetch = [&](int r0, int gs) {
         int ry = fy + r0;
-        ry = ry < 0 ? 0 : (ry > g.ny - 1 ? g.ny - 1 : ry);
+        ry = __builtin_elementwise_min(__builtin_elementwise_max(ry, 0), g.ny - 1);   // (v_max / v_min: a select costs five times as much)
         const int o = ry * pitch4 + fcol4;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(pr, (lds_t)&ring[gs][0][0][0][0], 16, o + fhalf, 0, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(fr, (lds_t)&ring[gs][1][0][0][0], 16, o + fhalf, 0, 0, 0);
@@ -222,6 +223,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int scol4 = (s * W + 1 + 4 * sgc) * 4;
     const int sy0 = sch ? yb : ya, sy1 = sch ? yend_b : yend_a;
     const int o_w = ((lane - lo) & 63);
+    const int s_drop = (s_full && (!WR || (sch ? act_b : act_a))) ? 0 : (int)0x80000000;   // bit 31: this lane never stores a full four
 
     // Level T of the chunk's rows 0 .. Lc - 1 needs level t of rows -(T - t) .. Lc - 1 + (T - t): the first row to take is -T (its
     // CQ is row -T + 1's coe8), the last tick is the one of row Lc - 1 + T; whole groups of two rows (the second sends the results)
@@ -358,7 +360,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     // (WR: nothing of a stopped member is written, as k_sweep_q's residual-writing launch skips it)
                     const bool okr = r_ >= sy0 && r_ < sy1 && (!WR || (sch ? act_b : act_a));
                     const int off = r_ * pitch4 + scol4 + (sch ? dmo4 : 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(v, outr, (okr && s_full) ? off : (int)0x80000000, 0, 0);
+                    // a lane with nothing to store aims out of range (bit 31): its row outside the chunk -- the sign of
+                    // (r_ - sy0) | (sy1 - 1 - r_) -- or its four columns not all its strip's, or (WR) its member stopped (s_drop).
+                    // Arithmetic, not a select: v_cndmask_b32 costs 23 cycles on this chip against 3 for an add (profiles/r01 ubench)
+                    const int off_full = off | ((((r_ - sy0) | (sy1 - 1 - r_)) | s_drop) & (int)0x80000000);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, outr, off_full, 0, 0);
                     if (nvalid & 3) {                     // (the last strip only) the columns of a partial four, one by one
 #pragma unroll
                         for (int k = 0; k < 3; ++k)
@@ -366,8 +372,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     }
                     if constexpr (WR) {
                         const u4 vr = *(const u4*)&robuf[sch][srow][4 * sgc];
-                        __builtin_amdgcn_raw_buffer_store_b128(vr, resr, (okr && s_full) ? off : (int)0x80000000, 0, 0);
-                        if (snap) __builtin_amdgcn_raw_buffer_store_b128(v, snapr, (okr && s_full) ? off : (int)0x80000000, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(vr, resr, off_full, 0, 0);
+                        if (snap) __builtin_amdgcn_raw_buffer_store_b128(v, snapr, off_full, 0, 0);
                         if (nvalid & 3) {
 #pragma unroll
                             for (int k = 0; k < 3; ++k) {
@@ -383,6 +389,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 }
                 // ---- the new row's weights take a free slot
                 const bool ia = col_int && rowa >= 1 && rowa <= g.ny - 2, ib = col_int && rowb >= 1 && rowb <= g.ny - 2;
+                // y1 = interior ? q : -0 without a select (v_cndmask_b32 costs 23 cycles on this chip, an and / or 3: profiles/r01 ubench):
+                // (q & m) | z with m = all ones, z = 0 where the point is interior, else m = 0, z = the bits of -0.  The masks come from the
+                // signs of (x - lo) | (hi - x) and pass an empty asm statement, or the compiler turns them back into selects.
+                auto pick = [&](float qv, int row) -> float {
+                    int m = ~(((row - 1) | (g.ny - 2 - row)) >> 31) & (int)cmask;   // all ones: row and column interior
+                    asm volatile("" : "+v"(m));
+                    return __builtin_bit_cast(float, (__builtin_bit_cast(int, qv) & m) | (~m & (int)0x80000000));
+                };
                 const WT am = zshrW(ap);
                 WT c5;
                 if constexpr (!NINE) {
@@ -407,11 +421,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 cq_prev = cq; by_prev = by;
                 if constexpr (MP) {                       // (the two halves are the same points of two members: ia = ib)
                     if constexpr (EXACT) y1[slot] = ia ? 1.0f : 0.0f;
-                    else y1[slot] = ia ? quotient_y1(-c5) : -0.0f;
+                    else y1[slot] = pick(quotient_y1(-c5), rowa);
                     (void)ib;
                 } else {
                     if constexpr (EXACT) y1[slot] = f2{ia ? 1.0f : 0.0f, ib ? 1.0f : 0.0f};
-                    else y1[slot] = f2{ia ? quotient_y1(-c5.x) : -0.0f, ib ? quotient_y1(-c5.y) : -0.0f};
+                    else y1[slot] = f2{pick(quotient_y1(-c5.x), rowa), pick(quotient_y1(-c5.y), rowb)};
                 }
                 ff[slot] = fa;
                 if constexpr (!EXACT) lds_wait(np, nx);   // the next tick's row has arrived (LDS returns in order)
