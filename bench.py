@@ -328,13 +328,14 @@ def main():
         streamed = z_launches * 2 > launches and z_timed > 0
         kernel_label = f"{info['name']} (damped-Jacobi sweep, {tb_T} iteration(s) per launch, tile {info['tile']})"
         if streamed:
-            kernel, tb_T = "k_sweep_z", 6
+            kernel, tb_T = "k_sweep_z", (6 if operator == "BAROTROPIC" else 4)
             avg_launch_s = z_ms * 1e-3 / max(z_timed / streams, 1)
             if z_launches == launches:
                 kernel_label = (f"{info['name']} (damped-Jacobi sweep streamed along z: all {launches} sweep launches -- per check block of 100 "
-                                f"iterations 16 launches of 6 and one of 4 that also writes the residual)")
+                                + ("iterations 16 launches of 6 and one of 4 that also writes the residual)" if tb_T == 6 else
+                                   "iterations 25 launches of 4, the last of which also writes the residual)"))
             else:
-                kernel_label = (f"k_sweep_z<star> (damped-Jacobi sweep streamed along z, 6 iterations per launch: {z_launches} of the "
+                kernel_label = (f"{info['name']} (damped-Jacobi sweep streamed along z, {tb_T} iterations per launch: {z_launches} of the "
                                 f"{launches} sweep launches; the others -- each check block's residual-writing launch and a remainder "
                                 f"-- are k_sweep_q's)")
         ent = traffic_entry(kernel, nr, nz, members_per_launch, operator)
@@ -374,7 +375,7 @@ def main():
         common = {"kernel": kernel_label, "avg_launch_us": avg_launch_s * 1e6, "launches": launches, "concurrent_launches": streams,
                   "members_per_launch": members_per_launch, "point_iterations_per_launch": point_iters / max(launches, 1),
                   "traffic_source": traffic_source, "hbm": hbm}
-        if streamed and n_shared == 0:
+        if streamed and (n_shared == 0 or operator == "BAROCLINIC"):
             # algorithmic bytes of one launch (20 B per point and pass x its points) over its measured
             # duration, all concurrent launches together.  Cross-check: every sweep launch of the timed region is one pass
             # over the planes, so their bytes over the sweeps' device time is a second, coarser figure (it includes the longer
@@ -386,7 +387,10 @@ def main():
             roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
                     "achieved_from_kernel_launches": gbs_z, "achieved_from_all_sweep_launches": gbs_all,
                     "frac_of_measured_copy_peak": gbs / 6290.0,
-                    "why_hbm": "with the arithmetic taken out the walk takes 85 % of its time (4.9 TB/s); profiles/r03/z_ablation.txt",
+                    "why_hbm": ("with the arithmetic taken out the walk takes 85 % of its time (4.9 TB/s); profiles/r03/z_ablation.txt" if operator == "BAROTROPIC" else
+                                "four iterations per pass over psi, f, BX, BY of every member (20 B per point; six do not fit the registers): the measured "
+                                "traffic over the launch time is the rate at which the star's walk saturates with its arithmetic taken out (4.5 - 4.9 TB/s; "
+                                "profiles/r03/z_ablation.txt, profiles/r03/README.md)"),
                     "z_launches": z_launches, "z_timed_launches": z_timed, "valu": valu, **common}
         else:
             # k_sweep_q everywhere; and k_sweep_z once the members share AP and CQ: 12.5 instead of 20 B per point and pass leave

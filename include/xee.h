@@ -61,10 +61,12 @@ int         xee_device_count(int *count);  /* number of visible HIP devices (0 i
  *                      division (k_sweep_tb4) | 3 generating planes, hoisted reciprocal (k_sweep_q) | 4 as 3, with the plain
  *                      launches streamed along z by single waves (k_sweep_z) wherever that kernel applies.  Auto is 3
  *                      whenever xee_ensemble_assemble / xee_cal_coe built the planes, and 4 for a batch that fills the
- *                      device with k_sweep_z (e.g. 32 cases of 1024x512): BAROTROPIC operator, alpha = 1, every member's
+ *                      device with k_sweep_z (e.g. 32 cases of 1024x512): BAROTROPIC operator -- or BAROCLINIC, for members
+ *                      that all share A and C (generating planes AP, CQ; each may have its own B) --, alpha = 1, every member's
  *                      |coe5| within [2^-120, 2^120] and its smallest interior |forcing| at least 2^26 times
- *                      max(2^-100, max |coe5| 2^-120) -- tested per solve (one pass over three planes); the residual-writing
- *                      launch of every check block stays k_sweep_q's
+ *                      max(2^-100, max |coe5| 2^-120) -- tested per solve (one pass over three planes).  Launches of 6 iterations
+ *                      (BAROCLINIC: 4); the residual-writing launch of a check block too where the block is whole launches
+ *                      (100 = 16 x 6 + 4 = 25 x 4), else it stays k_sweep_q's
  *   "z_pairs"          chunks of rows per strip of k_sweep_z, in pairs: 1..64, 0 = chosen from the batch (0)
  *   "share_planes"     0: every member reads its own copy of the operator's generating planes even where all members hold the
  *                      same ones (1: such planes are read from one copy -- tested once per assembled operator)
@@ -289,7 +291,7 @@ typedef struct {
                                   sweep_launches counts both halves' launches (each over half the members) and sweep_ms is the
                                   longer of the two halves' sweep times -- the average duration of one launch, as a profiler
                                   sees it, is sweep_ms / (sweep_launches / sweep_streams) */
-    int64_t z_launches;        /* of sweep_launches: launches of the streaming k_sweep_z (large BAROTROPIC batches; the others of
+    int64_t z_launches;        /* of sweep_launches: launches of the streaming k_sweep_z (large batches; the others of
                                   such a solve -- the residual-writing launch of every check block and a remainder -- are
                                   k_sweep_q's) */
     double  z_ms;              /* device time between the first and the last k_sweep_z launch of every check block (HIP events on the

@@ -125,18 +125,21 @@ def test_streamed_large_batch_with_a_shared_operator_against_the_reference_files
         assert H.md5(psi[m]) == gold[f"member{m}_1024x512_200"]["md5"]["rchi-[BAROTROPIC]-O.bin"], m
 
 
-def test_member_pairs_walk_special_values_and_exact_body():
+@pytest.mark.parametrize("variant", [0, 1])
+def test_member_pairs_walk_special_values_and_exact_body(variant):
     """Where all members share AP and CQ, k_sweep_z walks the same chunk of TWO members in the two halves of its register pairs
     (an odd last member with itself).  Three members: one plain, one with -0 on its rim and inside its first guess, one whose
     first guess overflows -- the wave that holds the -0 / the non-finite value takes the exact body for BOTH its members; and the
-    exact body alone; against the tiled sweep and against the chunk-paired walk (share_planes = 0)."""
+    exact body alone; against the tiled sweep and against the chunk-paired walk (share_planes = 0).  variant 1: the nine-weight
+    operator (BAROCLINIC), each member with its own B."""
     nr, nz, n = 170, 110, 40
     A, B, Cc, bc = H.rich_inputs(nr, nz, seed=23)
     rng = np.random.default_rng(8)
     f = ((0.5 + rng.random(A.shape)) * rng.choice([-1e-6, 1e-6], size=A.shape)).astype(np.float32)
     b1 = bc.copy(); b1[0, 60:64] = np.float32(-0.0); b1[50:52, 80:90] = np.float32(-0.0); b1[nz - 1, 100] = np.float32(-0.0)
     b2 = bc.copy(); b2[30:33, 40:50] = np.float32(3.0e38)
-    mem = [(A, B, Cc, bc), (A, B, Cc, b1), (A, B, Cc, b2)]
+    Bm = [B, B, B] if variant == 0 else [(B + np.float32(2e-3 * m) * rng.standard_normal(B.shape)).astype(np.float32) for m in range(3)]
+    mem = [(A, Bm[0], Cc, bc), (A, Bm[1], Cc, b1), (A, Bm[2], Cc, b2)]
 
     def run(opts):
         with xee.Ensemble(nr, nz, 3) as e:
@@ -146,7 +149,7 @@ def test_member_pairs_walk_special_values_and_exact_body():
             for m, (a_, b_, c_, bc_) in enumerate(mem):
                 for name, arr in (("A", a_), ("B", b_), ("C", c_), ("BC_INIT", bc_), ("FORCING", f * np.float32(1 + m))):
                     e.upload(name, arr, first=m)
-            e.assemble(0)
+            e.assemble(variant)
             with np.errstate(all="ignore"):
                 rec = e.solve(n, 1e-8, -1.0, 1.0)
             return e.download("PSI"), rec, e.timing(), e.sweep_info()
@@ -155,7 +158,11 @@ def test_member_pairs_walk_special_values_and_exact_body():
     assert not np.all(np.isfinite(want[2])) and np.all(np.isfinite(want[0])) and np.all(np.isfinite(want[1]))
     for opts in ({"kernel": 4}, {"kernel": 4, "q_exact_only": 1}, {"kernel": 4, "share_planes": 0}, {"kernel": 4, "z_pairs": 3}):
         got, rg, t, info = run(opts)
-        assert t["z_launches"] > 0 and t["shared_planes"] == (0 if opts.get("share_planes") == 0 else AP | CQ)
+        assert t["shared_planes"] == (0 if opts.get("share_planes") == 0 else AP | CQ)
+        if variant == 1 and opts.get("share_planes") == 0:
+            assert t["z_launches"] == 0                              # (the nine-weight operator streams for member pairs only)
+        else:
+            assert t["z_launches"] > 0 and info["name"].startswith("k_sweep_z<nine" if variant else "k_sweep_z<star"), info
         assert t["inline_redo_tiles"] > 0
         assert biteq(got[:2], want[:2]), opts                        # the finite members: bit for bit
         nan = np.isnan(want[2])
@@ -171,3 +178,68 @@ def test_member_pairs_every_member_count(M):
     assert t["z_launches"] > 0 and t["shared_planes"] == (AP | CQ) and t["inline_redo_tiles"] == 0
     ref, rr, _ = _solve(mem, 0, n, {"kernel": 3, "share_planes": 0})
     assert biteq(psi, ref) and rec["err_now"].tobytes() == rr["err_now"].tobytes() and rec["iters"].tolist() == rr["iters"].tolist()
+
+
+# ---- the nine-weight operator (BAROCLINIC) streamed: member pairs that share AP and CQ, BX and BY each member's own ------------------
+
+def _members9(nr, nz, M, share_b):
+    A0, B0, C0, bc0 = H.rich_inputs(nr, nz, seed=nr + 7)
+    rng = np.random.default_rng(3)
+    out = []
+    for m in range(M):
+        B = B0 if share_b else (B0 + np.float32(1e-3 * (m + 1)) * rng.standard_normal(B0.shape)).astype(np.float32)
+        out.append((A0, B, C0, (bc0 * np.float32(1.0 + 0.1 * m)).astype(np.float32)))
+    return out
+
+
+@pytest.mark.parametrize("nr,nz,n,M,share_b", [(200, 150, 106, 2, 0), (333, 270, 231, 3, 0), (67, 40, 120, 5, 1), (1000, 33, 250, 2, 0),
+                                               (57, 45, 66, 4, 0), (1024, 512, 208, 4, 0)])
+def test_nine_weight_operator_streams_for_member_pairs(nr, nz, n, M, share_b):
+    """k_sweep_z<nine> (four iterations per launch; the last launch of a check block also writes the residual) against
+    k_sweep_q<nine>, bit for bit: iterate, residual norms, stop iterations; with its exact body alone; other chunkings; and one
+    member against the oracle."""
+    mem = _members9(nr, nz, M, share_b)
+    want, rw, tw = _solve(mem, 1, n, {"kernel": 3})
+    assert tw["z_launches"] == 0
+    for opts in ({"kernel": 4}, {"kernel": 4, "q_exact_only": 1}, {"kernel": 4, "z_pairs": 3}, {"kernel": 4, "z_pairs": 1}):
+        got, rg, t = _solve(mem, 1, n, opts)
+        assert t["z_launches"] > 0 and t["shared_planes"] == (15 if share_b else AP | CQ), (opts, t)
+        assert (t["inline_redo_tiles"] > 0) == bool(opts.get("q_exact_only")), (opts, t)
+        assert biteq(got, want) and rg["err_now"].tobytes() == rw["err_now"].tobytes() and rg["iters"].tolist() == rw["iters"].tolist(), opts
+    if nr * nz <= 100000:
+        m = M - 1
+        A, B, Cc, bc = mem[m]
+        prof = H.profiles(nr, nz)
+        sA, sB, sC = H.solver_coefficients(A, B, Cc, prof["rcuva"], prof["rho"])
+        coe = H.cal_coe(sA, sB, sC, prof["dr"], prof["dz"], nr, nz)
+        o = H.solve(bc, coe, (-B).astype(np.float32), n, 1e-8, -1.0, 1.0)
+        assert biteq(got[m], o[0]) and int(rg["iters"][m]) == o[1]
+
+
+def test_nine_weight_members_that_stop_at_different_checks():
+    """Members leave at different checks: the residual-writing launch of k_sweep_z<nine> writes nothing of a stopped member, a
+    stopped member beside a running one in a pair is iterated on and its result stays its snapshot's."""
+    nr, nz, M, n = 300, 200, 6, 1500
+    mem = _members9(nr, nz, M, 0)
+
+    def run(opts, r1):
+        with xee.Ensemble(nr, nz, M) as e:
+            for k, v in opts.items():
+                e.set_option(k, v)
+            e.set_profiles(xee.profiles(nr, nz))
+            for m, (A, B, Cc, bc) in enumerate(mem):
+                for name, arr in (("A", A), ("B", B), ("C", Cc), ("BC_INIT", bc)):
+                    e.upload(name, arr, first=m)
+            e.forcing_from_B(); e.assemble(1)
+            rec = e.solve(n, r1, -1.0, 1.0, converge_time=1)
+            return rec.copy(), e.download("PSI"), e.download("RESIDUAL"), e.timing()
+
+    probe, _, _, _ = run({"kernel": 3}, 1e-30)
+    r1 = float(np.sort(probe["err_now"])[M // 2]) * 1.5          # between the members' residuals at the end: some stop early
+    rw, pw, resw, tw = run({"kernel": 3}, r1)
+    assert len(set(rw["iters"].tolist())) >= 3 and tw["z_launches"] == 0, rw["iters"]
+    for opts in ({"kernel": 4}, {"kernel": 4, "z_pairs": 2}):
+        rg, pg, resg, tg = run(opts, r1)
+        assert tg["z_launches"] > 0
+        assert rg["iters"].tolist() == rw["iters"].tolist() and rg["err_now"].tobytes() == rw["err_now"].tobytes(), (rg["iters"], rw["iters"])
+        assert biteq(pg, pw) and biteq(resg[:, 1:-1, 1:-1], resw[:, 1:-1, 1:-1])

@@ -105,7 +105,7 @@ def main():
         if short(kname) == "k_sweep_z":
             # the streaming sweep: one wave per (strip of 52 own columns, pair of chunks, member); every wave reads 64 columns of
             # its chunks' rows plus 2 T rows of run-in per chunk (and up to two fetch groups more), four planes
-            T, W = 6, 52
+            T, W = (6, 52) if op == "BAROTROPIC" else (4, 56)   # (the nine-weight operator: four iterations per launch)
             strips = -(-(nr - 2) // W)
             ML, P = M, 1
             for ml in (M, max(1, M // 2)):

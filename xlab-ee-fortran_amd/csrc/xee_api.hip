@@ -173,6 +173,7 @@ struct xee_ensemble {
     // k_sweep_z (xee_sweepz.hip): chunk pairs per strip while this solve's plain launches of sweep_z_T() iterations go to it
     // (0: they do not); the members' extremes of |coe5| and |f| that decide it (device, 3 words per member)
     int z_pairs_now = 0;
+    int z_T_now = 6;             // ... and their length: sweep_z_T(base_baro)
     unsigned* zstat = nullptr;
     bool base_shared_known = false;    // Grid.base_shared describes the current generating planes (else: tested at the next solve)
     unsigned* shared_differs = nullptr; // device word of the test
@@ -294,20 +295,25 @@ int base_shared_update(xee_ensemble* e)
 }
 
 // Whether this solve's plain launches go to the streaming k_sweep_z, and with how many chunk pairs per strip
-// (e->z_pairs_now): the star operator from the generating planes, alpha = 1, a launch of `members` cases beside `streams` - 1
+// (e->z_pairs_now): the operator from its generating planes (the star; nine weights where the members share AP and CQ), alpha = 1, a launch of `members` cases beside `streams` - 1
 // like it that fills the device (option "kernel" = 4: whatever it fills), and every member within the bounds under which the
 // kernel's hoisted division is the IEEE one (xee_sweepz.hip).  One pass over f, AP, CQ and a 12-byte-per-member copy.
 int z_decide(xee_ensemble* e, float alpha, int tb_T, int streams, int members)
 {
     e->z_pairs_now = 0;
     const int k = e->opts.kernel;
-    if (!(e->have_base && e->base_baro && alpha == 1.0f && (k == 0 || k == 4) && tb_T >= sweep_z_T())) return XEE_OK;
+    const int zT = sweep_z_T(e->base_baro);
+    e->z_T_now = zT;
+    if (!(e->have_base && alpha == 1.0f && (k == 0 || k == 4) && tb_T >= zT)) return XEE_OK;
+    // (the nine-weight operator is streamed for member pairs that share AP and CQ only)
+    if (!e->base_baro && !((e->g.base_shared & 3) == 3 && members >= 2)) return XEE_OK;
     if (e->g.plane * sizeof(float) >= ((size_t)1 << 31) - 64) return XEE_OK;       // (byte offsets inside a plane are 32-bit)
     // (measured end to end, tools/auto_vs_tiled.py, profiles/r03/auto_vs_tiled.txt.  Members that each read their own operator planes:
     // at 73 .. 75 the streamed solve is level with the tiled one or, for one 4096x2048 case, 4 - 8 % behind it, at 79 .. 82 it is
     // 10 % ahead: 78.  Members that share AP and CQ (one copy, walked in pairs): 8 - 13 % ahead at 73 already, 20 % behind at 41: 70.)
     const bool shared = (e->g.base_shared & 3) == 3 && members >= 2;
-    int P = sweep_z_pairs(e->g, members, streams, k == 4 ? 0 : (shared ? 70 : 78));
+    // (the nine-weight operator, profiles/r03/auto_vs_tiled.txt: 19 % ahead at 81, 11 % at 75, level at 71, 26 % behind at 43: 72)
+    int P = sweep_z_pairs(e->g, members, streams, k == 4 ? 0 : (!e->base_baro ? 72 : shared ? 70 : 78), zT);
     if (P > 0 && e->opts.z_pairs > 0) P = e->opts.z_pairs;
     if (P <= 0) return XEE_OK;
     if (!e->zstat) HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->zstat), 3 * sizeof(unsigned) * e->g.members));
@@ -375,8 +381,8 @@ bool launch_blocked(xee_ensemble* e, const float* psi_in, float* psi_out, float*
 {
     const int k = e->opts.kernel;
     if (!st) st = e->st;
-    if (e->z_pairs_now > 0 && alpha == 1.0f && sweep_z_can(T, res != nullptr)) {
-        launch_sweep_z(e->g, psi_in, psi_out, e->base, e->f, res, res ? snap : nullptr, st, T, e->z_pairs_now, e->opts.q_exact_only, e->redo,
+    if (e->z_pairs_now > 0 && alpha == 1.0f && sweep_z_can(T, res != nullptr, e->base_baro)) {
+        launch_sweep_z(e->g, psi_in, psi_out, e->base, e->f, res, res ? snap : nullptr, st, T, e->base_baro, e->z_pairs_now, e->opts.q_exact_only, e->redo,
                        &e->last_sweep, e->stream);
         return res != nullptr && snap != nullptr;           // (the residual-writing form also wrote the snapshot)
     }
@@ -644,7 +650,7 @@ int xee_ensemble_sweep_info(xee_ensemble_t* e, char* name, int name_len, int* T,
     if (!e) return fail(XEE_ERR_INVALID_ARGUMENT, "null ensemble");
     if (e->opts.T == 1) e->last_sweep = SweepDesc{"k_sweep_stream", 1, e->g.nx, e->g.ny};   // one iteration per launch, no tiles
     if (name && name_len > 0) { strncpy(name, e->last_sweep.name, (size_t)name_len - 1); name[name_len - 1] = 0; }
-    if (T) *T = e->opts.T;                      // the configured launch length (the last launch of a block may be shorter)
+    if (T) *T = e->z_pairs_now > 0 ? e->z_T_now : e->opts.T;   // the configured launch length (k_sweep_z: its own; the last launch of a block may be shorter)
     if (tile_w) *tile_w = e->last_sweep.tile_w;
     if (tile_h) *tile_h = e->last_sweep.tile_h;
     return XEE_OK;
@@ -977,14 +983,14 @@ int solve_pipelined(xee_ensemble* e, int max_iter, int cs, ConvParams cp, float 
     int z_enqueued = 0;                                   // k_sweep_z launches among those of the last enqueue_sweeps
     auto enqueue_sweeps = [&](int from, int target, bool to_check, int sl, int* cur_io, bool* snapped, int* launches, long long* tiles) {
         *snapped = false; *launches = 0; *tiles = 0; z_enqueued = 0;
-        plan_block(target - from, to_check, tb_T, e->z_pairs_now > 0 ? sweep_z_T() : 0, &plan);
+        plan_block(target - from, to_check, tb_T, e->z_pairs_now > 0 ? e->z_T_now : 0, &plan);
         // (large batches: the block's run of k_sweep_z launches between its own pair of events -- xee_timing_t.z_ms)
         const bool time_z = block_events && to_check;
         bool z_open = false;
         for (size_t i = 0; i < plan.size(); ++i) {
             const int n = plan[i];
             const bool check = to_check && i + 1 == plan.size();
-            const bool will_stream = e->z_pairs_now > 0 && alpha == 1.0f && sweep_z_can(n, check);
+            const bool will_stream = e->z_pairs_now > 0 && alpha == 1.0f && sweep_z_can(n, check, e->base_baro);
             if (time_z && will_stream && !z_open) { hipEventRecord(e->evZ[sl][0], s); z_open = true; }
             if (z_open && !will_stream) { hipEventRecord(e->evZ[sl][1], s); z_open = false; }
             e->last_sweep.tiles = 0; e->last_sweep.streamed = false;
@@ -1387,7 +1393,7 @@ void aim_half_view(xee_ensemble* e, xee_ensemble* s, int m0)
     s->coe = e->coe + off; s->base = e->base ? e->base + off : nullptr;
     s->st = e->st + m0; s->st_host = e->st_host + m0; s->ex_slow = e->ex_slow + m0; s->redo = e->redo;
     s->cur = e->cur; s->opts = e->opts; s->have_base = e->have_base; s->base_baro = e->base_baro; s->uv = e->uv;
-    s->z_pairs_now = e->z_pairs_now; s->g.base_shared = e->g.base_shared;
+    s->z_pairs_now = e->z_pairs_now; s->z_T_now = e->z_T_now; s->g.base_shared = e->g.base_shared;
     s->exact_serial = e->exact_serial; s->sync_checks = e->sync_checks;
 }
 
@@ -1786,7 +1792,7 @@ int xee_ensemble_time_sweeps(xee_ensemble_t* e, int iters, int variant, float al
     e->z_pairs_now = 0;
     XCHK(base_shared_update(e));
     if (variant == 1 && e->opts.kernel == 4) XCHK(z_decide(e, alpha, e->opts.T, 1, g.members));
-    const int len = e->z_pairs_now > 0 ? sweep_z_T() : e->opts.T;
+    const int len = e->z_pairs_now > 0 ? e->z_T_now : e->opts.T;
     HIPCHK(hipEventRecord(e->ev[0], s));
     for (int k = 0; k < iters;) {
         const int n = variant == 0 ? 1 : ((iters - k) < len ? (iters - k) : len);

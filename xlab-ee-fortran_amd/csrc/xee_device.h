@@ -147,15 +147,15 @@ void launch_quotient_check(unsigned long long seed, int blocks, int per_thread, 
                            hipStream_t s);
 // large batches, star operator, alpha = 1, plain launches: the blocked sweep streamed along z by single waves
 // (xee_sweepz.hip); bit-identical to launch_sweep_q where z_member_ok holds for every member
-int  sweep_z_T();                                         // iterations per launch (6)
-int  sweep_z_pairs(const Grid& g, int members, int streams, int min_eff_percent);   // chunk pairs per strip, 0 = "use k_sweep_q"
+int  sweep_z_T(bool barotropic);                          // iterations per launch: 6, nine-weight operator (member pairs that share AP, CQ) 4
+int  sweep_z_pairs(const Grid& g, int members, int streams, int min_eff_percent, int T);   // chunk pairs per strip, 0 = "use k_sweep_q"
 void launch_z_extremes(const Grid& g, const float* base, const float* f, unsigned* zstat /* device, 3 per member */, hipStream_t s);
 bool z_member_ok(const unsigned* zstat3 /* host copy of one member's three words */);
-bool sweep_z_can(int T, bool with_residual);            // 6 iterations plain; 6 or 4 with the residual of the last one
+bool sweep_z_can(int T, bool with_residual, bool barotropic);   // star: 6 iterations plain, 6 or 4 with the residual of the last one; nine weights: 4
 void launch_sweep_z(const Grid& g, const float* psi_in, float* psi_out, const float* base, const float* f,
                     float* res /* nullptr, or the residual plane of the launch's last iteration ... */,
                     float* snap /* ... and (or nullptr) a second copy of the new iterate's interior, active members only */,
-                    const MemberState* st, int T, int chunk_pairs, int exact_only,
+                    const MemberState* st, int T, bool barotropic, int chunk_pairs, int exact_only,
                     int* diag /* device, 2 ints or nullptr: [1] counts the waves that fell back to the exact body */,
                     SweepDesc* desc, hipStream_t s);
 int  tb_max_T();

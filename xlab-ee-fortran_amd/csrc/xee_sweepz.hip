@@ -25,9 +25,10 @@
 // below): the VALU then bounds the walk (10.4 us per iteration of 32 cases with the memory operations removed, 11 - 12 with
 // them).  DESIGN.md "The streaming sweep" has the numbers.
 //
-// BAROTROPIC operator (five-point star from the two generating planes AP, CQ), alpha = 1, plain launches (no residual
-// plane): the host (xee_api.hip) gives the residual-writing launch at the end of a check block and any remainder to
-// k_sweep_q.  Results are bit-identical to k_sweep_q's and the reference's:
+// BAROTROPIC operator (five-point star from the two generating planes AP, CQ) or, for member pairs that share AP and CQ, the
+// nine-weight BAROCLINIC one (B9 below); alpha = 1; plain launches and the residual-writing launch at the end of a check block
+// (WR below); the host (xee_api.hip) gives a remainder that is no whole launch to k_sweep_q.  Results are bit-identical to
+// k_sweep_q's and the reference's:
 //   * the division is k_sweep_q's hoisted reciprocal (y1 once per row, five operations per point), exact for every quotient
 //     whose operands pass the bounds that k_sweep_q checks per tile.  Here the HOST checks them per member before a solve
 //     (k_z_extremes: |coe5| in [2^-120, 2^120] and min |f| 2^-26 >= max(2^-100, max |coe5| 2^-120), which puts every non-zero
@@ -39,9 +40,11 @@
 //     their quotient is a zero whatever their "residual", and psi + (+-0) = psi unless psi is -0;
 //   * a wave that loaded a -0 or stored a non-finite value walks its chunks again with the exact body: the reference's
 //     nine-term sum in its order, the IEEE division, idle points by selection -- k_sweep_q's exact_tile, streamed.
-// The nine-weight operator (BAROCLINIC) was built on the same walk and dropped: 22 registers of weights per row in flight
-// spill at T = 6, and a spill's reload drains the prefetch queue (33.5 against k_sweep_q's 28.0 us per iteration;
-// tools/experiments/sweepz_two_kernels_and_nine_weight.hip.txt).
+// The nine-weight operator (BAROCLINIC): 16 registers of weights per row in flight (eight pairs; coe5 and y1 are one value for a
+// pair of members that share AP and CQ) fit at T = 4 (236 VGPRs, no spill; at T = 6 they spill, and a spill's reload drains the
+// prefetch queue: the first attempt, tools/experiments/sweepz_two_kernels_and_nine_weight.hip.txt, lost to k_sweep_q).  20 bytes per
+// point and launch (psi, f, BX, BY in, psi out) for four iterations: HBM-bound, 22.2 against k_sweep_q<nine>'s 27.2 us per iteration
+// of 32 cases (profiles/r03/z_ablation.txt).
 #include "xee_device.h"
 
 #include <cfloat>
@@ -117,7 +120,9 @@ __device__ __forceinline__ void z_for(F&& body) { z_for_impl(body, std::make_int
 // WR: the launch at the end of a check block -- the residual of its LAST iteration (do_elliptic(psi) - f, elliptic_tools.f90:189-190)
 // goes to `res` and a second copy of the new iterate to `snap` (may be null), for the members that are active (a stopped member's
 // snapshot is its result: nothing of it may be written).
-template <int T, bool MP, bool WR>
+// B9: the nine-weight operator (BAROCLINIC: BX, BY are read too) for member pairs that share AP and CQ -- coe5 and y1 stay one value
+// for both halves, the other eight weights are a pair; T = 4 (at T = 6 the weights of the eight rows in flight do not fit 256 registers).
+template <int T, bool MP, bool WR, bool B9 = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sweep_z(Grid g, const float* __restrict__ psi_in, float* __restrict__ psi_out,
         const float* __restrict__ base, const float* __restrict__ f, const MemberState* __restrict__ st, int nstrip, int P, int Lc, int nunits,
         int exact_only, int* __restrict__ diag, float* __restrict__ res, float* __restrict__ snap)
@@ -128,8 +133,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     constexpr int U = (S % 4 == 0) ? S : 2 * S;           // (... and of the four places the psi rows rotate through)
     constexpr int W = 64 - 2 * T;
     static_assert(W % 4 == 0 && U % 2 == 0 && U % S == 0, "the 16-byte stores take the strip's own columns in fours");
-    constexpr int NF = MP ? 3 : 4;                        // fetch instructions per group: psi, f, AP, CQ (MP: AP and CQ in one)
-    constexpr int DG = MP ? 4 : 3;                        // groups in flight ahead of the one being read
+    static_assert(!B9 || MP, "the nine-weight walk is built for member pairs");
+    constexpr int NF = B9 ? 5 : (MP ? 3 : 4);             // fetch instructions per group: psi, f, AP, CQ (MP: AP and CQ in one) (, BX, BY)
+    constexpr int DG = B9 ? 2 : (MP ? 4 : 3);             // groups in flight ahead of the one being read (20 KB of LDS per wave at most)
     constexpr int NG = DG + 1;                            // groups in LDS
     __shared__ __attribute__((aligned(16))) float ring[NG][NF][2][2][64];   // [group][plane][chunk or member][row][column]: 4 KB (MP: 3 KB) per group
     __shared__ __attribute__((aligned(16))) float obuf[2][2][64];
@@ -159,6 +165,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int dcq4 = MP ? (int)(ks * 4) : 0;
     const rsrc_t pr = zrsrc(psi_in + mo, g, 16 + dmo4), fr = zrsrc(f + mo, g, 16 + dmo4);
     const rsrc_t apr = zrsrc(base + ((g.base_shared & 1) ? 0 : mo), g, 16 + dcq4), cqr = zrsrc(base + ks + ((g.base_shared & 2) ? 0 : mo), g, 16);
+    // (B9) BX, BY: each member's own unless all share them
+    const int dbx4 = (g.base_shared & 4) ? 0 : dmo4, dby4 = (g.base_shared & 8) ? 0 : dmo4;
+    const rsrc_t bxr = zrsrc(base + (B9 ? 2 * ks + ((g.base_shared & 4) ? 0 : mo) : 0), g, 16 + dbx4);
+    const rsrc_t byr = zrsrc(base + (B9 ? 3 * ks + ((g.base_shared & 8) ? 0 : mo) : 0), g, 16 + dby4);
     const rsrc_t outr = zrsrc(psi_out + mo, g, dmo4);
     const rsrc_t resr = zrsrc((WR ? res : psi_out) + mo, g, dmo4), snapr = zrsrc((WR && snap ? snap : psi_out) + mo, g, dmo4);
     const int ya = 1 + c * Lc, yb = MP ? ya : 1 + (c + P) * Lc;
@@ -169,13 +179,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // this lane's part of a fetch: row (lane >> 4) & 1 of the group, of chunk lane >> 5, 16 bytes from column x0 + 4 (lane & 15)
     const int fy = (lane >= 32 ? yb : ya) + ((lane >> 4) & 1), fcol4 = (x0 + 4 * (lane & 15)) * 4;
     const int fhalf = lane >= 32 ? dmo4 : 0, fac4 = lane >= 32 ? dcq4 : 0;   // MP: the second half's member / CQ behind AP
+    const int fbx = lane >= 32 ? dbx4 : 0, fby = lane >= 32 ? dby4 : 0;
     auto fetch = [&](int r0, int gs) {
         int ry = fy + r0;
         ry = __builtin_elementwise_min(__builtin_elementwise_max(ry, 0), g.ny - 1);   // (v_max / v_min: a select costs five times as much)
         const int o = ry * pitch4 + fcol4;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(pr, (lds_t)&ring[gs][0][0][0][0], 16, o + fhalf, 0, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(fr, (lds_t)&ring[gs][1][0][0][0], 16, o + fhalf, 0, 0, 0);
-        if constexpr (MP) __builtin_amdgcn_raw_ptr_buffer_load_lds(apr, (lds_t)&ring[gs][2][0][0][0], 16, o + fac4, 0, 0, 0);
+        if constexpr (B9) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(apr, (lds_t)&ring[gs][2][0][0][0], 16, o + fac4, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(bxr, (lds_t)&ring[gs][3][0][0][0], 16, o + fbx, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(byr, (lds_t)&ring[gs][4][0][0][0], 16, o + fby, 0, 0, 0);
+        } else if constexpr (MP) __builtin_amdgcn_raw_ptr_buffer_load_lds(apr, (lds_t)&ring[gs][2][0][0][0], 16, o + fac4, 0, 0, 0);
         else {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(apr, (lds_t)&ring[gs][2][0][0][0], 16, o, 0, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(cqr, (lds_t)&ring[gs][NF - 1][0][0][0], 16, o, 0, 0, 0);
@@ -185,11 +200,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // LDS latency hides behind a tick of arithmetic.  Inline assembly: the compiler cannot tell the slot an LDS-DMA fetch
     // fills from the slot read here and would drain vmcnt(0) in front of every read of this array that it can see (measured:
     // 15.7 -> 22.6 us).  [chunk][row][64]: row r of chunk a at offset r (x 64 dwords), of chunk b at 2 + r; plane k at 4 k.
-    struct Fac { f2 f, a, c; };                           // (MP: a = {AP, CQ} of the row, c unused)
+    struct Fac { f2 f, a, c, bx, by; };                   // (MP: a = {AP, CQ} of the row, c unused; bx, by: B9 only)
     auto lds_issue = [&](f2& np, Fac& nx, int gs, auto sub_tag) {
         constexpr int r = decltype(sub_tag)::value;
         const unsigned ad = (unsigned)(size_t)(lds_t)&ring[gs][0][0][0][lane];
-        if constexpr (MP)
+        if constexpr (B9)
+            asm volatile("ds_read2st64_b32 %0, %5 offset0:%6 offset1:%7\n\t"
+                         "ds_read2st64_b32 %1, %5 offset0:%8 offset1:%9\n\t"
+                         "ds_read2st64_b32 %2, %5 offset0:%10 offset1:%11\n\t"
+                         "ds_read2st64_b32 %3, %5 offset0:%12 offset1:%13\n\t"
+                         "ds_read2st64_b32 %4, %5 offset0:%14 offset1:%15"
+                         : "=&v"(np), "=&v"(nx.f), "=&v"(nx.a), "=&v"(nx.bx), "=&v"(nx.by)
+                         : "v"(ad), "n"(r), "n"(r + 2), "n"(r + 4), "n"(r + 6), "n"(r + 8), "n"(r + 10), "n"(r + 12), "n"(r + 14),
+                           "n"(r + 16), "n"(r + 18) : "memory");
+        else if constexpr (MP)
             asm volatile("ds_read2st64_b32 %0, %3 offset0:%4 offset1:%5\n\t"
                          "ds_read2st64_b32 %1, %3 offset0:%6 offset1:%7\n\t"
                          "ds_read2st64_b32 %2, %3 offset0:%8 offset1:%9"
@@ -209,7 +233,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // be scheduled across the wait; tests/test_sweepz_isa.py checks what came out.)
     auto lds_wait = [&](const f2& np, const Fac& nx) {
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (MP) asm volatile("s_waitcnt lgkmcnt(0)" : : "v"(np), "v"(nx.f), "v"(nx.a) : "memory");
+        if constexpr (B9) asm volatile("s_waitcnt lgkmcnt(0)" : : "v"(np), "v"(nx.f), "v"(nx.a), "v"(nx.bx), "v"(nx.by) : "memory");
+        else if constexpr (MP) asm volatile("s_waitcnt lgkmcnt(0)" : : "v"(np), "v"(nx.f), "v"(nx.a) : "memory");
         else asm volatile("s_waitcnt lgkmcnt(0)" : : "v"(np), "v"(nx.f), "v"(nx.a), "v"(nx.c) : "memory");
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -232,21 +257,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 
     auto walk = [&](auto exact_tag) -> bool {
         constexpr bool EXACT = decltype(exact_tag)::value;
-        constexpr bool NINE = EXACT;                      // the exact body keeps all nine weights of a row; else the star's AP, CQ, coe5
+        constexpr bool NINE = EXACT || B9;                // the exact body keeps all nine weights of a row (b = 0 unless B9); else the star's AP, CQ, coe5
         constexpr int NW9 = NINE ? 9 : 3;
         // w[k][slot]: NINE: coe1 .. coe9 (w[4] = coe5); else w[0] = AP, w[1] = CQ, w[2] = coe5.  y1: the optimistic body's
         // reciprocal, -0 where the point never updates; the exact body keeps 1 / 0 ("updates" / "idle") there instead.
         using WT = std::conditional_t<MP, float, f2>;    // a row's weights: per chunk, or one for both members
+        using WW = std::conditional_t<B9, f2, WT>;        // ... except coe5 and y1, a pair where the members have their own BX, BY
         const WT zeroW = WT{};
-        WT w[NW9][S], y1[S];
+        const WW zeroWW = WW{};
+        auto ww = [](auto v) -> WW { if constexpr (std::is_same_v<decltype(v), WW>) return v; else return WW{v, v}; };
+        WW w[NW9][S];
+        WT y1[S];
         f2 ff[S];
         f2 hist[T][2];
-        WT cq_prev = zeroW, by_prev = zeroW;              // the row before the newest: its CQ and BY make the new row's weights
+        WT cq_prev = zeroW;                               // the row before the newest: its CQ and BY make the new row's weights
+        WW by_prev = zeroWW;
 #pragma unroll
         for (int k = 0; k < S; ++k) {
             y1[k] = zeroW; ff[k] = f2{0.f, 0.f};
 #pragma unroll
-            for (int q = 0; q < NW9; ++q) w[q][k] = zeroW;
+            for (int q = 0; q < NW9; ++q) w[q][k] = zeroWW;
         }
 #pragma unroll
         for (int l = 0; l < T; ++l) hist[l][0] = hist[l][1] = f2{0.f, 0.f};
@@ -277,7 +307,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 if constexpr (MP) { ap = fac[u & 1].a.x; cq = fac[u & 1].a.y; } else { ap = fac[u & 1].a; cq = fac[u & 1].c; }
                 f2& np = psr[(u + 1) & 3];                // where the next tick's row goes
                 Fac& nx = fac[(u + 1) & 1];
-                const WT bx = zeroW, by = zeroW;              // (b = 0: what the exact body's nine weights are made of besides AP, CQ)
+                WW bx = zeroWW, by = zeroWW;              // (b = 0 unless B9: what the nine weights are made of besides AP, CQ)
+                if constexpr (B9) { bx = fac[u & 1].bx; by = fac[u & 1].by; }
                 if constexpr (sub == 0) {
                     // a group starts: the slot of the group before it is free (its last row was read two ticks ago) and takes the
                     // group DG ahead; the next tick's row is this group's second, in LDS since this group's first was read
@@ -401,21 +432,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 WT c5;
                 if constexpr (!NINE) {
                     c5 = -(am + ap + cq_prev + cq);       // elliptic_tools.f90:50, left to right
-                    w[0][slot] = ap;
-                    w[1][slot] = cq;
-                    w[2][slot] = c5;
+                    w[0][slot] = ww(ap);
+                    w[1][slot] = ww(cq);
+                    w[2][slot] = ww(c5);
                 } else {
                     // elliptic_tools.f90:46-54 with b = 0, every term kept so that the zeros' signs are the reference's (as exact_tile, xee_sweepq.hip)
-                    const WT bxm = zshrW(bx), bym = by_prev, cm = cq_prev;
+                    const WW bxm = zshrW(bx), bym = by_prev;
+                    const WT cm = cq_prev;
                     c5 = -(am + ap + cm + cq);
                     w[0][slot] = -(bxm + by);
-                    w[1][slot] = cq + (bx - bxm);
+                    w[1][slot] = ww(cq) + (bx - bxm);
                     w[2][slot] = bx + by;
-                    w[3][slot] = am - (by - bym);
-                    w[4][slot] = c5;
-                    w[5][slot] = ap + (by - bym);
+                    w[3][slot] = ww(am) - (by - bym);
+                    w[4][slot] = ww(c5);
+                    w[5][slot] = ww(ap) + (by - bym);
                     w[6][slot] = bxm + bym;
-                    w[7][slot] = cm - (bx - bxm);
+                    w[7][slot] = ww(cm) - (bx - bxm);
                     w[8][slot] = -(bx + bym);
                 }
                 cq_prev = cq; by_prev = by;
@@ -499,17 +531,18 @@ bool z_member_ok(const unsigned* zstat3)
 }
 
 
-int sweep_z_T() { return 6; }
+int sweep_z_T(bool barotropic) { return barotropic ? 6 : 4; }
 
 // Chunk pairs per strip for a launch over `members` cases that shares the device with `streams` - 1 launches like it.
 // The device holds 2048 waves of this kernel (eight per CU); a launch of n waves takes ceil(n / places) rounds, and a
 // chunk of Lc rows costs Lc + 2 T ticks: the P in 1 .. (ny - 2) / 64 with the largest product of the rounds' filling
 // and Lc / (Lc + 2 T).  Returns 0 where that product is below `min_eff_percent`: k_sweep_q's tiles use the device better
 // there (the caller's thresholds are measured end to end, profiles/r03/auto_vs_tiled.txt: 32 cases of 1024x512 reach 82, 24 cases 79,
-// 16 cases and 4 cases of 2048x1024 73, one case of 4096x2048 75, 8 cases of 1024x512 41).
-int sweep_z_pairs(const Grid& g, int members, int streams, int min_eff_percent)
+// 16 cases and 4 cases of 2048x1024 73, one case of 4096x2048 75, 8 cases of 1024x512 41; T = 4, the nine-weight operator: 81, 75
+// for 32, 16 cases, 71 for 12, 43 for 8).
+int sweep_z_pairs(const Grid& g, int members, int streams, int min_eff_percent, int T)
 {
-    constexpr int T = 6, W = 64 - 2 * T;
+    const int W = 64 - 2 * T;
     if (g.nx < 8 || g.ny < 8 || members < 1) return 0;
     const long long strips = (g.nx - 2 + W - 1) / W;
     const long long places = 2048 / (streams > 0 ? streams : 1);
@@ -526,10 +559,10 @@ int sweep_z_pairs(const Grid& g, int members, int streams, int min_eff_percent)
     return best_eff * 100.0 >= (double)min_eff_percent ? best : 0;
 }
 
-bool sweep_z_can(int T, bool with_residual) { return T == 6 || (with_residual && T == 4); }
+bool sweep_z_can(int T, bool with_residual, bool barotropic) { return barotropic ? (T == 6 || (with_residual && T == 4)) : T == 4; }
 
 void launch_sweep_z(const Grid& g, const float* psi_in, float* psi_out, const float* base, const float* f, float* res, float* snap,
-                    const MemberState* st, int T, int P, int exact_only, int* diag, SweepDesc* desc, hipStream_t s)
+                    const MemberState* st, int T, bool barotropic, int P, int exact_only, int* diag, SweepDesc* desc, hipStream_t s)
 {
     const int W = 64 - 2 * T;
     const int nstrip = (g.nx - 2 + W - 1) / W;
@@ -538,12 +571,17 @@ void launch_sweep_z(const Grid& g, const float* psi_in, float* psi_out, const fl
     const size_t ks = g.kstride ? g.kstride : (size_t)g.members * g.plane;
     const bool pairs = (g.base_shared & 3) == 3 && g.members >= 2 && (ks + g.plane) * 4 + 64 < ((size_t)1 << 31);
     const long long units = pairs ? (long long)nstrip * 2 * P * ((g.members + 1) / 2) : (long long)nstrip * P * g.members;
-    if (desc) { desc->name = pairs ? "k_sweep_z<star, member pairs>" : "k_sweep_z<star>"; desc->T = T; desc->tile_w = 64; desc->tile_h = Lc; desc->tiles = units; desc->streamed = true; }
+    if (desc) { desc->name = !barotropic ? "k_sweep_z<nine, member pairs>" : pairs ? "k_sweep_z<star, member pairs>" : "k_sweep_z<star>"; desc->T = T; desc->tile_w = 64; desc->tile_h = Lc; desc->tiles = units; desc->streamed = true; }
     // (T = 8 was measured too: 17.3 against 17.6 us per iteration at equal P -- what it saves in bytes it pays in halo and run-in,
     // and its 22 strips leave no P that fills the 2048 places; profiles/r03/z_ablation.txt)
     const dim3 grid((unsigned)(8 * ((units + 7) / 8)));
 #define XEE_Z_LAUNCH(TT, MPAIR, WRES) hipLaunchKernelGGL((k_sweep_z<TT, MPAIR, WRES>), grid, dim3(64), 0, s, g, psi_in, psi_out, base, f, st, nstrip, P, Lc, (int)units, exact_only, diag, res, snap)
-    if (!res) { if (pairs) XEE_Z_LAUNCH(6, true, false); else XEE_Z_LAUNCH(6, false, false); }
+    if (!barotropic) {                                    // (z_decide sends the nine-weight operator here for member pairs only)
+        if (!pairs || T != 4) return;
+        if (res) hipLaunchKernelGGL((k_sweep_z<4, true, true, true>), grid, dim3(64), 0, s, g, psi_in, psi_out, base, f, st, nstrip, P, Lc, (int)units, exact_only, diag, res, snap);
+        else hipLaunchKernelGGL((k_sweep_z<4, true, false, true>), grid, dim3(64), 0, s, g, psi_in, psi_out, base, f, st, nstrip, P, Lc, (int)units, exact_only, diag, res, snap);
+    }
+    else if (!res) { if (pairs) XEE_Z_LAUNCH(6, true, false); else XEE_Z_LAUNCH(6, false, false); }
     else if (T == 4) { if (pairs) XEE_Z_LAUNCH(4, true, true); else XEE_Z_LAUNCH(4, false, true); }
     else { if (pairs) XEE_Z_LAUNCH(6, true, true); else XEE_Z_LAUNCH(6, false, true); }
 #undef XEE_Z_LAUNCH
