@@ -243,3 +243,38 @@ def test_nine_weight_members_that_stop_at_different_checks():
         assert tg["z_launches"] > 0
         assert rg["iters"].tolist() == rw["iters"].tolist() and rg["err_now"].tobytes() == rw["err_now"].tobytes(), (rg["iters"], rw["iters"])
         assert biteq(pg, pw) and biteq(resg[:, 1:-1, 1:-1], resw[:, 1:-1, 1:-1])
+
+
+def test_nine_weight_b_sums_the_hoisted_division_cannot_take_stay_tiled():
+    """k_sweep_z<nine> makes BX and BY itself from the solver coefficient b, dividing by the hoisted reciprocal: exact for +0 and for
+    sums well inside the normal range.  A member whose b holds -0 (the division would give +0) or subnormal values keeps
+    the batch on the tiled sweep; zeros (+0) in b stream.  Results equal the tiled sweep's either way."""
+    nr, nz, n, M = 180, 120, 60, 3
+    base = _members9(nr, nz, M, 0)
+
+    def with_b(m, fn):
+        mem = [list(x) for x in base]
+        B = mem[m][1].copy(); fn(B); mem[m][1] = B
+        return [tuple(x) for x in mem]
+
+    def patch(v):
+        def f(B): B[30:50, 60:100] = np.float32(v)
+        return f
+    def run(mem, opts):                                   # (the forcing from the unpatched B: no zeros in it)
+        with xee.Ensemble(nr, nz, M) as e:
+            for k, v in opts.items():
+                e.set_option(k, v)
+            e.set_profiles(xee.profiles(nr, nz))
+            for m, (A, B, Cc, bc) in enumerate(mem):
+                for name, arr in (("A", A), ("B", B), ("C", Cc), ("BC_INIT", bc), ("FORCING", (-base[m][1]).astype(np.float32))):
+                    e.upload(name, arr, first=m)
+            e.assemble(1)
+            rec = e.solve(n, 1e-8, -1.0, 1.0)
+            return e.download("PSI"), rec, e.timing()
+
+    for fn, streams in ((patch(0.0), True), (patch(-0.0), False), (patch(1e-45), False), (patch(1e-12), True)):
+        mem = with_b(1, fn)
+        want, rw, _ = run(mem, {"kernel": 3})
+        got, rg, t = run(mem, {"kernel": 4})
+        assert (t["z_launches"] > 0) == streams, (streams, t)
+        assert biteq(got, want) and rg["err_now"].tobytes() == rw["err_now"].tobytes()

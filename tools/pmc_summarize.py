@@ -106,6 +106,8 @@ def main():
             # the streaming sweep: one wave per (strip of 52 own columns, pair of chunks, member); every wave reads 64 columns of
             # its chunks' rows plus 2 T rows of run-in per chunk (and up to two fetch groups more), four planes
             T, W = (6, 52) if op == "BAROTROPIC" else (4, 56)   # (the nine-weight operator: four iterations per launch)
+            if op != "BAROTROPIC":
+                planes = 5                                        # psi, f, AP, CQ and b (it makes BX and BY itself)
             strips = -(-(nr - 2) // W)
             ML, P = M, 1
             for ml in (M, max(1, M // 2)):

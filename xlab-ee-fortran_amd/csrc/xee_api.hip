@@ -282,7 +282,7 @@ int base_shared_update(xee_ensemble* e)
     e->g.base_shared = 0;
     e->base_shared_known = true;
     if (!e->opts.share_planes) return XEE_OK;
-    const int nplanes = e->base_baro ? 2 : 4;
+    const int nplanes = e->base_baro ? 2 : 5;             // (AP, CQ | BX, BY and the copy of b)
     const unsigned all = (1u << nplanes) - 1u;
     if (e->g.members < 2) { e->g.base_shared = (int)all; return XEE_OK; }
     if (!e->shared_differs) HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->shared_differs), sizeof(unsigned)));
@@ -316,13 +316,13 @@ int z_decide(xee_ensemble* e, float alpha, int tb_T, int streams, int members)
     int P = sweep_z_pairs(e->g, members, streams, k == 4 ? 0 : (!e->base_baro ? 72 : shared ? 70 : 78), zT);
     if (P > 0 && e->opts.z_pairs > 0) P = e->opts.z_pairs;
     if (P <= 0) return XEE_OK;
-    if (!e->zstat) HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->zstat), 3 * sizeof(unsigned) * e->g.members));
-    launch_z_extremes(e->g, e->base, e->f, e->zstat, e->stream);
-    std::vector<unsigned> h(3 * (size_t)e->g.members);
+    if (!e->zstat) HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->zstat), 6 * sizeof(unsigned) * e->g.members));
+    launch_z_extremes(e->g, e->base, e->f, e->base_baro, e->zstat, e->stream);
+    std::vector<unsigned> h(6 * (size_t)e->g.members);
     HIPCHK(hipMemcpyAsync(h.data(), e->zstat, h.size() * sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     for (int m = 0; m < e->g.members; ++m)
-        if (!z_member_ok(&h[3 * (size_t)m])) return XEE_OK;
+        if (!z_member_ok(&h[6 * (size_t)m], e->base_baro, e->g.two_pq4)) return XEE_OK;
     e->z_pairs_now = P;
     return XEE_OK;
 }
@@ -823,7 +823,8 @@ int xee_ensemble_assemble(xee_ensemble_t* e, int variant)
     launch_cal_coe(e->g, e->sA, variant == XEE_BAROCLINIC ? e->sB : nullptr, e->sC, e->coe, e->dr, e->dz, e->stream);
     XCHK(check_launch("assemble"));
     XCHK(detect_uniform_planes(e));
-    XCHK(alloc_planes(e, &e->base, 4));
+    XCHK(alloc_planes(e, &e->base, 5));
+    e->g.two_pq4 = 2.0f * (4.0f * e->dr * e->dz);
     launch_base_planes(e->g, e->sA, variant == XEE_BAROCLINIC ? e->sB : nullptr, e->sC, e->base, e->dr, e->dz, e->stream);
     XCHK(check_launch("base planes"));
     e->have_base = true;
@@ -839,7 +840,8 @@ int xee_ensemble_assemble_solver(xee_ensemble_t* e, int use_b)
     launch_cal_coe(e->g, e->sA, use_b ? e->sB : nullptr, e->sC, e->coe, e->dr, e->dz, e->stream);
     XCHK(check_launch("assemble_solver"));
     XCHK(detect_uniform_planes(e));
-    XCHK(alloc_planes(e, &e->base, 4));
+    XCHK(alloc_planes(e, &e->base, 5));
+    e->g.two_pq4 = 2.0f * (4.0f * e->dr * e->dz);
     launch_base_planes(e->g, e->sA, use_b ? e->sB : nullptr, e->sC, e->base, e->dr, e->dz, e->stream);
     XCHK(check_launch("base planes"));
     e->have_base = true;
@@ -1393,7 +1395,7 @@ void aim_half_view(xee_ensemble* e, xee_ensemble* s, int m0)
     s->coe = e->coe + off; s->base = e->base ? e->base + off : nullptr;
     s->st = e->st + m0; s->st_host = e->st_host + m0; s->ex_slow = e->ex_slow + m0; s->redo = e->redo;
     s->cur = e->cur; s->opts = e->opts; s->have_base = e->have_base; s->base_baro = e->base_baro; s->uv = e->uv;
-    s->z_pairs_now = e->z_pairs_now; s->z_T_now = e->z_T_now; s->g.base_shared = e->g.base_shared;
+    s->z_pairs_now = e->z_pairs_now; s->z_T_now = e->z_T_now; s->g.base_shared = e->g.base_shared; s->g.two_pq4 = e->g.two_pq4;
     s->exact_serial = e->exact_serial; s->sync_checks = e->sync_checks;
 }
 
@@ -1744,7 +1746,7 @@ int xee_ensemble_timing(xee_ensemble_t* e, xee_timing_t* out)
 {
     if (!e || !out) return fail(XEE_ERR_INVALID_ARGUMENT, "null argument");
     *out = e->timing;
-    out->shared_planes = e->base_shared_known ? e->g.base_shared : 0;
+    out->shared_planes = e->base_shared_known ? (e->g.base_shared & 15) : 0;
     return XEE_OK;
 }
 
@@ -1987,7 +1989,8 @@ int cache_try(xee_ensemble* e)
     HIPCHK(hipMemcpyAsync(&differs, e->uv_differs, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     if (differs) return XEE_OK;
-    XCHK(alloc_planes(e, &e->base, 4));
+    XCHK(alloc_planes(e, &e->base, 5));
+    e->g.two_pq4 = 2.0f * (4.0f * cc.dx * cc.dy);
     launch_base_planes(e->g, cc.abc, cc.b_zero ? nullptr : cc.abc + e->g.plane, cc.abc + 2 * e->g.plane, e->base, cc.dx, cc.dy, e->stream);
     XCHK(check_launch("base planes (Tier 1)"));
     e->have_base = true;

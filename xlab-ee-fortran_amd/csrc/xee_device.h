@@ -22,7 +22,8 @@ struct Grid {
     size_t plane;    // floats per member per field = pitch * ny
     size_t kstride;  // floats between planes k and k + 1 of the SoA fields (coe, base); 0 = members * plane.  Non-zero in the
                      // view of a member sub-range that xee_ensemble_solve hands to one of its two sweep streams (k_sweep_q only)
-    int base_shared; // bit k: generating plane k (AP, CQ, BX, BY) holds the same bits for every member -- members that share
+    float two_pq4;   // 2 (4 dx dy), as cal_coe rounds it (elliptic_tools.f90:31-32): BX, BY = (b + b') / two_pq4 (k_base_planes; k_sweep_z<nine> divides itself)
+    int base_shared; // bit k: generating plane k (AP, CQ, BX, BY; 4: the solver coefficient b they are made of) holds the same bits for every member -- members that share
                      // their operator, e.g. an ensemble that varies the forcing only -- so k_sweep_q / k_sweep_z read member 0's
                      // copy for all of them (4 MB that stay in the caches instead of 8 B per point and pass from HBM)
 };
@@ -149,8 +150,8 @@ void launch_quotient_check(unsigned long long seed, int blocks, int per_thread, 
 // (xee_sweepz.hip); bit-identical to launch_sweep_q where z_member_ok holds for every member
 int  sweep_z_T(bool barotropic);                          // iterations per launch: 6, nine-weight operator (member pairs that share AP, CQ) 4
 int  sweep_z_pairs(const Grid& g, int members, int streams, int min_eff_percent, int T);   // chunk pairs per strip, 0 = "use k_sweep_q"
-void launch_z_extremes(const Grid& g, const float* base, const float* f, unsigned* zstat /* device, 3 per member */, hipStream_t s);
-bool z_member_ok(const unsigned* zstat3 /* host copy of one member's three words */);
+void launch_z_extremes(const Grid& g, const float* base, const float* f, bool barotropic, unsigned* zstat /* device, 6 per member */, hipStream_t s);
+bool z_member_ok(const unsigned* zstat6 /* host copy of one member's six words */, bool barotropic, float two_pq4);
 bool sweep_z_can(int T, bool with_residual, bool barotropic);   // star: 6 iterations plain, 6 or 4 with the residual of the last one; nine weights: 4
 void launch_sweep_z(const Grid& g, const float* psi_in, float* psi_out, const float* base, const float* f,
                     float* res /* nullptr, or the residual plane of the launch's last iteration ... */,

@@ -36,7 +36,7 @@ __device__ __forceinline__ float shl1(float src)   // lane l <- lane l+1 (lane 6
 
 }  // namespace
 
-// the four generating planes from the solver coefficients (the divisions of elliptic_tools.f90:37-44)
+// the four generating planes from the solver coefficients (the divisions of elliptic_tools.f90:37-44), and a copy of b as a fifth
 __global__ __launch_bounds__(256) void k_base_planes(Grid g, const float* __restrict__ a, const float* __restrict__ b,
         const float* __restrict__ c, float* __restrict__ base, float dx, float dy)
 {
@@ -60,6 +60,7 @@ __global__ __launch_bounds__(256) void k_base_planes(Grid g, const float* __rest
     base[o + ks] = cq;
     base[o + 2 * ks] = bx;
     base[o + 3 * ks] = by;
+    base[o + 4 * ks] = b ? b[o] : 0.f;                    // (k_sweep_z<nine> reads b and divides itself: one plane instead of BX and BY)
 }
 
 template <int NW, int R, bool WRITE_R, bool BARO>

@@ -120,8 +120,10 @@ __device__ __forceinline__ void z_for(F&& body) { z_for_impl(body, std::make_int
 // WR: the launch at the end of a check block -- the residual of its LAST iteration (do_elliptic(psi) - f, elliptic_tools.f90:189-190)
 // goes to `res` and a second copy of the new iterate to `snap` (may be null), for the members that are active (a stopped member's
 // snapshot is its result: nothing of it may be written).
-// B9: the nine-weight operator (BAROCLINIC: BX, BY are read too) for member pairs that share AP and CQ -- coe5 and y1 stay one value
-// for both halves, the other eight weights are a pair; T = 4 (at T = 6 the weights of the eight rows in flight do not fit 256 registers).
+// B9: the nine-weight operator (BAROCLINIC) for member pairs that share AP and CQ -- coe5 and y1 stay one value for both halves, the
+// other eight weights are a pair; T = 4 (at T = 6 the weights of the eight rows in flight do not fit 256 registers).  The walk is
+// HBM-bound then, so it reads the solver coefficient b (k_base_planes keeps a copy as the fifth generating plane) instead of BX and
+// BY and makes the two itself, by cal_coe's own divisions (elliptic_tools.f90:41-44): 16 instead of 20 bytes per point and launch.
 template <int T, bool MP, bool WR, bool B9 = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sweep_z(Grid g, const float* __restrict__ psi_in, float* __restrict__ psi_out,
         const float* __restrict__ base, const float* __restrict__ f, const MemberState* __restrict__ st, int nstrip, int P, int Lc, int nunits,
@@ -134,8 +136,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     constexpr int W = 64 - 2 * T;
     static_assert(W % 4 == 0 && U % 2 == 0 && U % S == 0, "the 16-byte stores take the strip's own columns in fours");
     static_assert(!B9 || MP, "the nine-weight walk is built for member pairs");
-    constexpr int NF = B9 ? 5 : (MP ? 3 : 4);             // fetch instructions per group: psi, f, AP, CQ (MP: AP and CQ in one) (, BX, BY)
-    constexpr int DG = B9 ? 2 : (MP ? 4 : 3);             // groups in flight ahead of the one being read (20 KB of LDS per wave at most)
+    constexpr int NF = B9 ? 4 : (MP ? 3 : 4);             // fetch instructions per group: psi, f, AP, CQ (MP: AP and CQ in one; B9: and b)
+    constexpr int DG = (MP && !B9) ? 4 : 3;               // groups in flight ahead of the one being read (20 KB of LDS per wave at most)
     constexpr int NG = DG + 1;                            // groups in LDS
     __shared__ __attribute__((aligned(16))) float ring[NG][NF][2][2][64];   // [group][plane][chunk or member][row][column]: 4 KB (MP: 3 KB) per group
     __shared__ __attribute__((aligned(16))) float obuf[2][2][64];
@@ -165,10 +167,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int dcq4 = MP ? (int)(ks * 4) : 0;
     const rsrc_t pr = zrsrc(psi_in + mo, g, 16 + dmo4), fr = zrsrc(f + mo, g, 16 + dmo4);
     const rsrc_t apr = zrsrc(base + ((g.base_shared & 1) ? 0 : mo), g, 16 + dcq4), cqr = zrsrc(base + ks + ((g.base_shared & 2) ? 0 : mo), g, 16);
-    // (B9) BX, BY: each member's own unless all share them
-    const int dbx4 = (g.base_shared & 4) ? 0 : dmo4, dby4 = (g.base_shared & 8) ? 0 : dmo4;
-    const rsrc_t bxr = zrsrc(base + (B9 ? 2 * ks + ((g.base_shared & 4) ? 0 : mo) : 0), g, 16 + dbx4);
-    const rsrc_t byr = zrsrc(base + (B9 ? 3 * ks + ((g.base_shared & 8) ? 0 : mo) : 0), g, 16 + dby4);
+    // (B9) b, the fifth generating plane: each member's own unless all share it
+    const int dbx4 = (g.base_shared & 16) ? 0 : dmo4;
+    const rsrc_t bxr = zrsrc(base + (B9 ? 4 * ks + ((g.base_shared & 16) ? 0 : mo) : 0), g, 16 + dbx4);
     const rsrc_t outr = zrsrc(psi_out + mo, g, dmo4);
     const rsrc_t resr = zrsrc((WR ? res : psi_out) + mo, g, dmo4), snapr = zrsrc((WR && snap ? snap : psi_out) + mo, g, dmo4);
     const int ya = 1 + c * Lc, yb = MP ? ya : 1 + (c + P) * Lc;
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // this lane's part of a fetch: row (lane >> 4) & 1 of the group, of chunk lane >> 5, 16 bytes from column x0 + 4 (lane & 15)
     const int fy = (lane >= 32 ? yb : ya) + ((lane >> 4) & 1), fcol4 = (x0 + 4 * (lane & 15)) * 4;
     const int fhalf = lane >= 32 ? dmo4 : 0, fac4 = lane >= 32 ? dcq4 : 0;   // MP: the second half's member / CQ behind AP
-    const int fbx = lane >= 32 ? dbx4 : 0, fby = lane >= 32 ? dby4 : 0;
+    const int fbx = lane >= 32 ? dbx4 : 0;
     auto fetch = [&](int r0, int gs) {
         int ry = fy + r0;
         ry = __builtin_elementwise_min(__builtin_elementwise_max(ry, 0), g.ny - 1);   // (v_max / v_min: a select costs five times as much)
@@ -189,7 +190,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         if constexpr (B9) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(apr, (lds_t)&ring[gs][2][0][0][0], 16, o + fac4, 0, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(bxr, (lds_t)&ring[gs][3][0][0][0], 16, o + fbx, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(byr, (lds_t)&ring[gs][4][0][0][0], 16, o + fby, 0, 0, 0);
         } else if constexpr (MP) __builtin_amdgcn_raw_ptr_buffer_load_lds(apr, (lds_t)&ring[gs][2][0][0][0], 16, o + fac4, 0, 0, 0);
         else {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(apr, (lds_t)&ring[gs][2][0][0][0], 16, o, 0, 0, 0);
@@ -200,20 +200,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // LDS latency hides behind a tick of arithmetic.  Inline assembly: the compiler cannot tell the slot an LDS-DMA fetch
     // fills from the slot read here and would drain vmcnt(0) in front of every read of this array that it can see (measured:
     // 15.7 -> 22.6 us).  [chunk][row][64]: row r of chunk a at offset r (x 64 dwords), of chunk b at 2 + r; plane k at 4 k.
-    struct Fac { f2 f, a, c, bx, by; };                   // (MP: a = {AP, CQ} of the row, c unused; bx, by: B9 only)
+    struct Fac { f2 f, a, c; };                           // (MP: a = {AP, CQ} of the row, c unused -- B9: the two members' b)
     auto lds_issue = [&](f2& np, Fac& nx, int gs, auto sub_tag) {
         constexpr int r = decltype(sub_tag)::value;
         const unsigned ad = (unsigned)(size_t)(lds_t)&ring[gs][0][0][0][lane];
-        if constexpr (B9)
-            asm volatile("ds_read2st64_b32 %0, %5 offset0:%6 offset1:%7\n\t"
-                         "ds_read2st64_b32 %1, %5 offset0:%8 offset1:%9\n\t"
-                         "ds_read2st64_b32 %2, %5 offset0:%10 offset1:%11\n\t"
-                         "ds_read2st64_b32 %3, %5 offset0:%12 offset1:%13\n\t"
-                         "ds_read2st64_b32 %4, %5 offset0:%14 offset1:%15"
-                         : "=&v"(np), "=&v"(nx.f), "=&v"(nx.a), "=&v"(nx.bx), "=&v"(nx.by)
-                         : "v"(ad), "n"(r), "n"(r + 2), "n"(r + 4), "n"(r + 6), "n"(r + 8), "n"(r + 10), "n"(r + 12), "n"(r + 14),
-                           "n"(r + 16), "n"(r + 18) : "memory");
-        else if constexpr (MP)
+        if constexpr (MP && !B9)
             asm volatile("ds_read2st64_b32 %0, %3 offset0:%4 offset1:%5\n\t"
                          "ds_read2st64_b32 %1, %3 offset0:%6 offset1:%7\n\t"
                          "ds_read2st64_b32 %2, %3 offset0:%8 offset1:%9"
@@ -233,8 +224,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // be scheduled across the wait; tests/test_sweepz_isa.py checks what came out.)
     auto lds_wait = [&](const f2& np, const Fac& nx) {
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (B9) asm volatile("s_waitcnt lgkmcnt(0)" : : "v"(np), "v"(nx.f), "v"(nx.a), "v"(nx.bx), "v"(nx.by) : "memory");
-        else if constexpr (MP) asm volatile("s_waitcnt lgkmcnt(0)" : : "v"(np), "v"(nx.f), "v"(nx.a) : "memory");
+        if constexpr (MP && !B9) asm volatile("s_waitcnt lgkmcnt(0)" : : "v"(np), "v"(nx.f), "v"(nx.a) : "memory");
         else asm volatile("s_waitcnt lgkmcnt(0)" : : "v"(np), "v"(nx.f), "v"(nx.a), "v"(nx.c) : "memory");
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -272,6 +262,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         f2 hist[T][2];
         WT cq_prev = zeroW;                               // the row before the newest: its CQ and BY make the new row's weights
         WW by_prev = zeroWW;
+        f2 b_prev = f2{0.f, 0.f};                         // (B9) b of the row before the newest
+        const float yd_b = quotient_y1(g.two_pq4);
+        const f2 y1_b = f2{yd_b, yd_b}, nd_b = f2{-g.two_pq4, -g.two_pq4};   // (B9) BX, BY = (b + b') / (2 PQ4)
 #pragma unroll
         for (int k = 0; k < S; ++k) {
             y1[k] = zeroW; ff[k] = f2{0.f, 0.f};
@@ -308,7 +301,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 f2& np = psr[(u + 1) & 3];                // where the next tick's row goes
                 Fac& nx = fac[(u + 1) & 1];
                 WW bx = zeroWW, by = zeroWW;              // (b = 0 unless B9: what the nine weights are made of besides AP, CQ)
-                if constexpr (B9) { bx = fac[u & 1].bx; by = fac[u & 1].by; }
+                if constexpr (B9) {
+                    // elliptic_tools.f90:41-44: BX = (b(i,j) + b(i,j-1)) / (2 PQ4), BY = (b(i-1,j) + b(i,j)) / (2 PQ4) -- IEEE divisions, as k_base_planes makes them
+                    const f2 bc = fac[u & 1].c, sx = bc + b_prev, sy = zshr2(bc) + bc;
+                    if constexpr (EXACT) {
+                        bx = f2{sx.x / g.two_pq4, sx.y / g.two_pq4};
+                        by = f2{sy.x / g.two_pq4, sy.y / g.two_pq4};
+                    } else {
+                        // (the hoisted reciprocal again, 10 instead of 44 instructions per row: exact for the sums the host let
+                        // through -- k_z_extremes: +0, or dividend and quotient within [2^-100, 2^100], 2 PQ4 itself within [2^-60, 2^60])
+                        bx = z_q2(sx, nd_b, y1_b);
+                        by = z_q2(sy, nd_b, y1_b);
+                    }
+                    b_prev = bc;
+                }
                 if constexpr (sub == 0) {
                     // a group starts: the slot of the group before it is free (its last row was read two ticks ago) and takes the
                     // group DG ahead; the next tick's row is this group's second, in LDS since this group's first was read
@@ -481,6 +487,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // ---- per member: extremes of |coe5| and |f| over the interior (the host's test of k_sweep_z's preconditions) ------------------
 // zstat[m] = {min |coe5|, max |coe5|, min |f|} as the bits of non-negative floats (whose order is the order of the bits as
 // unsigned integers; a NaN sorts above infinity and so fails the test of the maximum).  Set to {~0, 0, ~0} before.
+// NINE: and {min, max} over the NON-ZERO |b + b'| that make BX and BY at the points the interior's weights take them from
+// (elliptic_tools.f90:41-44), and whether one of those sums is -0 -- k_sweep_z<nine> divides them by 2 PQ4 itself, by the hoisted
+// reciprocal, which turns a -0 into +0 and is not exact where the quotient leaves the normal range.
+template <bool NINE>
 __global__ __launch_bounds__(256) void k_z_extremes(Grid g, const float* __restrict__ base, const float* __restrict__ f, unsigned* __restrict__ zstat)
 {
     const int m = blockIdx.y;
@@ -488,46 +498,77 @@ __global__ __launch_bounds__(256) void k_z_extremes(Grid g, const float* __restr
     const float* __restrict__ ap = base + mo;
     const float* __restrict__ cq = base + ks + mo;
     const float* __restrict__ fm = f + mo;
-    unsigned dmin = 0xffffffffu, dmax = 0u, fmin = 0xffffffffu;
+    const float* __restrict__ bm = base + 4 * ks + ((g.base_shared & 16) ? 0 : mo);
+    unsigned dmin = 0xffffffffu, dmax = 0u, fmin = 0xffffffffu, smin = 0xffffffffu, smax = 0u, negz = 0u;
     for (int j = 1 + (int)blockIdx.x; j <= g.ny - 2; j += (int)gridDim.x)
         for (int i = 1 + (int)threadIdx.x; i <= g.nx - 2; i += 256) {
             const size_t o = (size_t)j * g.pitch + i;
             const float c5 = -(ap[o - 1] + ap[o] + cq[o - g.pitch] + cq[o]);   // elliptic_tools.f90:50 (b = 0)
             const unsigned d = __builtin_bit_cast(unsigned, c5) & 0x7fffffffu, a = __builtin_bit_cast(unsigned, fm[o]) & 0x7fffffffu;
             dmin = d < dmin ? d : dmin; dmax = d > dmax ? d : dmax; fmin = a < fmin ? a : fmin;
+            if constexpr (NINE) {
+                // BXp, BXm, BYp, BYm of this point: the sums behind BX(i,j), BX(i-1,j), BY(i,j), BY(i,j-1)
+                const float b00 = bm[o], bw = bm[o - 1], bs = bm[o - g.pitch], bsw = bm[o - g.pitch - 1];
+                const float sums[4] = {b00 + bs, bw + bsw, bw + b00, bsw + bs};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned u = __builtin_bit_cast(unsigned, sums[k]), v = u & 0x7fffffffu;
+                    negz |= (u == 0x80000000u) ? 1u : 0u;
+                    if (v) { smin = v < smin ? v : smin; smax = v > smax ? v : smax; }
+                }
+            }
         }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
         const unsigned a = __shfl_xor(dmin, o), b = __shfl_xor(dmax, o), c = __shfl_xor(fmin, o);
         dmin = a < dmin ? a : dmin; dmax = b > dmax ? b : dmax; fmin = c < fmin ? c : fmin;
+        if constexpr (NINE) {
+            const unsigned p = __shfl_xor(smin, o), q = __shfl_xor(smax, o);
+            smin = p < smin ? p : smin; smax = q > smax ? q : smax; negz |= __shfl_xor(negz, o);
+        }
     }
     if ((threadIdx.x & 63) == 0) {
-        atomicMin(&zstat[3 * m + 0], dmin);
-        atomicMax(&zstat[3 * m + 1], dmax);
-        atomicMin(&zstat[3 * m + 2], fmin);
+        atomicMin(&zstat[6 * m + 0], dmin);
+        atomicMax(&zstat[6 * m + 1], dmax);
+        atomicMin(&zstat[6 * m + 2], fmin);
+        if constexpr (NINE) {
+            atomicMin(&zstat[6 * m + 3], smin);
+            atomicMax(&zstat[6 * m + 4], smax);
+            if (negz) atomicOr(&zstat[6 * m + 5], 1u);
+        }
     }
 }
 
 __global__ void k_z_extremes_init(unsigned* __restrict__ zstat, int members)
 {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m < members) { zstat[3 * m + 0] = 0xffffffffu; zstat[3 * m + 1] = 0u; zstat[3 * m + 2] = 0xffffffffu; }
+    if (m < members) { zstat[6 * m + 0] = 0xffffffffu; zstat[6 * m + 1] = 0u; zstat[6 * m + 2] = 0xffffffffu;
+                       zstat[6 * m + 3] = 0xffffffffu; zstat[6 * m + 4] = 0u; zstat[6 * m + 5] = 0u; }
 }
 
-void launch_z_extremes(const Grid& g, const float* base, const float* f, unsigned* zstat, hipStream_t s)
+void launch_z_extremes(const Grid& g, const float* base, const float* f, bool barotropic, unsigned* zstat, hipStream_t s)
 {
     hipLaunchKernelGGL(k_z_extremes_init, dim3((g.members + 63) / 64), dim3(64), 0, s, zstat, g.members);
     const int by = g.ny - 2 < 64 ? (g.ny - 2 < 1 ? 1 : g.ny - 2) : 64;
-    hipLaunchKernelGGL(k_z_extremes, dim3(by, g.members), dim3(256), 0, s, g, base, f, zstat);
+    if (barotropic) hipLaunchKernelGGL(k_z_extremes<false>, dim3(by, g.members), dim3(256), 0, s, g, base, f, zstat);
+    else hipLaunchKernelGGL(k_z_extremes<true>, dim3(by, g.members), dim3(256), 0, s, g, base, f, zstat);
 }
 
 // the host's reading of k_z_extremes for one member (see the header of this file)
-bool z_member_ok(const unsigned* zstat3)
+bool z_member_ok(const unsigned* zstat3, bool barotropic, float two_pq4)
 {
     const float dmin = __builtin_bit_cast(float, zstat3[0]), dmax = __builtin_bit_cast(float, zstat3[1]), fmin = __builtin_bit_cast(float, zstat3[2]);
     if (!(dmin >= 0x1p-120f) || !(dmax <= 0x1p120f)) return false;       // (false for a NaN too)
     const float a_lo = dmax * 0x1p-120f > 0x1p-100f ? dmax * 0x1p-120f : 0x1p-100f;
-    return fmin * 0x1p-26f >= a_lo;
+    if (!(fmin * 0x1p-26f >= a_lo)) return false;
+    if (barotropic) return true;
+    // the nine-weight walk's own BX, BY = (b + b') / (2 PQ4): divisor, dividends and quotients well inside the normal range, no -0
+    if (!(two_pq4 >= 0x1p-60f) || !(two_pq4 <= 0x1p60f) || zstat3[5]) return false;
+    if (zstat3[4] == 0u) return true;                                     // every sum is +0
+    const float smin = __builtin_bit_cast(float, zstat3[3]), smax = __builtin_bit_cast(float, zstat3[4]);
+    // (dividend and quotient at least 2^-100: the remainders a - d q of the two correction steps are exact, nothing is subnormal)
+    const float s_lo = two_pq4 > 1.0f ? two_pq4 * 0x1p-100f : 0x1p-100f, s_hi = two_pq4 < 1.0f ? two_pq4 * 0x1p100f : 0x1p100f;
+    return smin >= s_lo && smax <= s_hi;
 }
 
 
