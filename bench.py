@@ -209,6 +209,8 @@ def main():
                          "(configs[4]: per timestep {L(B=0), L(B)} x {-B, thermal, zero RHS with a rim boundary}) | sor (OPT-IN, "
                          "non-parity: the red/black SOR smoother run to the residual the reference's 100,000 Jacobi iterations reach)")
     ap.add_argument("--omega", type=float, default=1.992, help="--workload sor: over-relaxation factor (optimal for 1024x512: 1.9923)")
+    ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE", help="library option for the timed ensemble (xee.h: every "
+                    "combination gives the same bits; for probing), repeatable")
     ap.add_argument("--sweep-split", action="store_true", help="--workload sweep: six (operator, kind) stages one after the "
                     "other instead of one fused batch per operator -- slower, but per_stage then separates the kinds")
     args = ap.parse_args()
@@ -257,6 +259,8 @@ def main():
     operator = "BAROCLINIC" if args.workload == "baroclinic" else "BAROTROPIC"
     prof = xee.profiles(nr, nz, 0, 0, (0.0, 1.0, 0.0, 1.0))
     ens = xee.Ensemble(nr, nz, M, device=local_rank)
+    for kv in args.option:
+        ens.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     ens.set_profiles(prof)
     ens.set_case_ids(rank * M)
     for m in range(M):                         # inputs resident in HBM before the timed region
@@ -573,7 +577,8 @@ def bench_sweep(args, xee, torch, dist, rank, local_rank, world, rehearsal, coll
     from xlab_ee_fortran_amd import ensemble_dp as dp
     from xlab_ee_fortran_amd import sweep as S
     nr, nz, nt = args.nr, args.nz, args.members
-    sw = S.Sweep(nr, nz, range(rank * nt, (rank + 1) * nt), device=local_rank, fused=not args.sweep_split)
+    sw = S.Sweep(nr, nz, range(rank * nt, (rank + 1) * nt), device=local_rank, fused=not args.sweep_split,
+                 options={kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.option})
     comm, gather_via = make_record_comm(xee, dist, rank, local_rank, world, rehearsal)
 
     def keep(op, rhs, ens, first):                 # member 0 of the (BAROTROPIC, -B) kind, for the golden check (device copy)

@@ -296,3 +296,32 @@ def test_streamed_residual_writing_launch(members):
             assert tz["z_launches"] == tz["sweep_launches"] > 0, (cs, tz)
         else:                            # 50 = 7 x 6 + 8: the residual-writing launch is k_sweep_q's
             assert 0 < tz["z_launches"] == tz["sweep_launches"] - blocks, (cs, tz)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_members_that_cannot_stream_leave_the_others_streaming(variant):
+    """24 cases of 1024x512, the last 8 with a zero right-hand side (the rim-boundary kind of a source-term sweep, whose cases come last
+    in the batch: old-diagnose/diagnose.f90:548-568): the first 16 stream, the 8 take the tiled sweep, side by side -- the same bits
+    as the tiled sweep for all; both operators."""
+    nr, nz, M, n = 1024, 512, 24, 300
+    ins = [H.member_inputs(nr, nz, m) for m in range(M)]
+    outs = {}
+    for tag, opts in (("auto", {}), ("tiled", {"kernel": 3}), ("one", {"split_halves": 0})):
+        with xee.Ensemble(nr, nz, M) as e:
+            for k, v in opts.items():
+                e.set_option(k, v)
+            e.set_profiles(xee.profiles(nr, nz))
+            for m, (A, B, Cc, bc) in enumerate(ins):
+                f = (-B).astype(np.float32) if m < 16 else np.zeros_like(B)
+                for name, arr in (("A", A), ("B", B), ("C", Cc), ("BC_INIT", bc), ("FORCING", f)):
+                    e.upload(name, arr, first=m)
+            e.assemble(variant)
+            rec = e.solve(n, 1e-8, -1.0, 1.0)
+            outs[tag] = (e.download("PSI"), rec.copy(), e.timing())
+    pa, ra, ta = outs["auto"]
+    assert ta["sweep_streams"] == 2 and 0 < ta["z_launches"] < ta["sweep_launches"], ta
+    assert ta["z_launches"] == 3 * (17 if variant == 0 else 25)
+    for tag in ("tiled", "one"):
+        pb, rb, tb = outs[tag]
+        assert tb["z_launches"] == 0 and tb["sweep_streams"] == 1
+        assert biteq(pa, pb) and ra["err_now"].tobytes() == rb["err_now"].tobytes() and ra["iters"].tolist() == rb["iters"].tolist(), tag

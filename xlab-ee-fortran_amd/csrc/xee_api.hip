@@ -298,9 +298,23 @@ int base_shared_update(xee_ensemble* e)
 // (e->z_pairs_now): the operator from its generating planes (the star; nine weights where the members share AP and CQ), alpha = 1, a launch of `members` cases beside `streams` - 1
 // like it that fills the device (option "kernel" = 4: whatever it fills), and every member within the bounds under which the
 // kernel's hoisted division is the IEEE one (xee_sweepz.hip).  One pass over f, AP, CQ and a 12-byte-per-member copy.
-int z_decide(xee_ensemble* e, float alpha, int tb_T, int streams, int members)
+// *first_bad (if given): -1, or the first member outside those bounds when that alone keeps the batch off the stream -- the
+// solve may then stream the members before it and leave the others to the tiled sweep, side by side (xee_ensemble_solve)
+int z_threshold(const xee_ensemble* e, int members)
+{
+    // (measured end to end, tools/auto_vs_tiled.py, profiles/r03/auto_vs_tiled.txt.  Members that each read their own operator planes:
+    // at 73 .. 75 the streamed solve is level with the tiled one or, for one 4096x2048 case, 4 - 8 % behind it, at 79 .. 82 it is
+    // 10 % ahead: 78.  Members that share AP and CQ (one copy, walked in pairs): 8 - 13 % ahead at 73 already, 20 % behind at 41: 70.
+    // The nine-weight operator, profiles/r03/auto_vs_tiled_baroclinic.txt: 24 % ahead at 81, 8 % at 75, level at 71, 30 % behind at 43: 72)
+    if (e->opts.kernel == 4) return 0;
+    const bool shared = (e->g.base_shared & 3) == 3 && members >= 2;
+    return !e->base_baro ? 72 : shared ? 70 : 78;
+}
+
+int z_decide(xee_ensemble* e, float alpha, int tb_T, int streams, int members, int* first_bad = nullptr)
 {
     e->z_pairs_now = 0;
+    if (first_bad) *first_bad = -1;
     const int k = e->opts.kernel;
     const int zT = sweep_z_T(e->base_baro);
     e->z_T_now = zT;
@@ -308,12 +322,7 @@ int z_decide(xee_ensemble* e, float alpha, int tb_T, int streams, int members)
     // (the nine-weight operator is streamed for member pairs that share AP and CQ only)
     if (!e->base_baro && !((e->g.base_shared & 3) == 3 && members >= 2)) return XEE_OK;
     if (e->g.plane * sizeof(float) >= ((size_t)1 << 31) - 64) return XEE_OK;       // (byte offsets inside a plane are 32-bit)
-    // (measured end to end, tools/auto_vs_tiled.py, profiles/r03/auto_vs_tiled.txt.  Members that each read their own operator planes:
-    // at 73 .. 75 the streamed solve is level with the tiled one or, for one 4096x2048 case, 4 - 8 % behind it, at 79 .. 82 it is
-    // 10 % ahead: 78.  Members that share AP and CQ (one copy, walked in pairs): 8 - 13 % ahead at 73 already, 20 % behind at 41: 70.)
-    const bool shared = (e->g.base_shared & 3) == 3 && members >= 2;
-    // (the nine-weight operator, profiles/r03/auto_vs_tiled.txt: 19 % ahead at 81, 11 % at 75, level at 71, 26 % behind at 43: 72)
-    int P = sweep_z_pairs(e->g, members, streams, k == 4 ? 0 : (!e->base_baro ? 72 : shared ? 70 : 78), zT);
+    int P = sweep_z_pairs(e->g, members, streams, z_threshold(e, members), zT);
     if (P > 0 && e->opts.z_pairs > 0) P = e->opts.z_pairs;
     if (P <= 0) return XEE_OK;
     if (!e->zstat) HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->zstat), 6 * sizeof(unsigned) * e->g.members));
@@ -322,7 +331,7 @@ int z_decide(xee_ensemble* e, float alpha, int tb_T, int streams, int members)
     HIPCHK(hipMemcpyAsync(h.data(), e->zstat, h.size() * sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     for (int m = 0; m < e->g.members; ++m)
-        if (!z_member_ok(&h[6 * (size_t)m], e->base_baro, e->g.two_pq4)) return XEE_OK;
+        if (!z_member_ok(&h[6 * (size_t)m], e->base_baro, e->g.two_pq4)) { if (first_bad) *first_bad = m; return XEE_OK; }
     e->z_pairs_now = P;
     return XEE_OK;
 }
@@ -1448,13 +1457,27 @@ int xee_ensemble_solve(xee_ensemble_t* e, int max_iter, int check_step, int conv
         // the halves must themselves still be large batches)
         const bool split = !ran && !small && q_only && e->opts.split_halves && g.members >= 32 && max_iter > 0 && s != nullptr && !e->is_view;
         // plain launches by the streaming k_sweep_z where the batch fills the device with it and every member qualifies
-        if (!ran && max_iter > 0) XCHK(z_decide(e, alpha, tb_T, split ? 2 : 1, split ? (g.members + 1) / 2 : g.members));
-        if (split) {
-            const int n0 = (g.members + 1) / 2, n1 = g.members - n0;
+        int first_bad = -1;
+        if (!ran && max_iter > 0) XCHK(z_decide(e, alpha, tb_T, split ? 2 : 1, split ? (g.members + 1) / 2 : g.members, &first_bad));
+        // Only some members keep the batch off the stream (e.g. the zero-forcing kind of a source-term sweep, whose cases come
+        // last): the members before the first of them stream, the others take the tiled sweep, side by side
+        int z_split_pairs = 0;
+        if (e->z_pairs_now == 0 && first_bad >= 8 && !ran && !small && q_only && e->opts.split_halves && max_iter > 0 && s != nullptr && !e->is_view) {
+            Grid gv = g;
+            gv.members = first_bad;
+            // (chunked as if it had the device to itself: the tiled launches find room beside it, and once the shorter of the two streams
+            // is through the other has the device -- tools/elig_split_probe.py, 16 + 8 cases: 39.2 ms with 1920 waves, 47.5 with 960; 32 + 16:
+            // 1920 either way; the tiled sweep for all: 61.1 ms)
+            z_split_pairs = sweep_z_pairs(gv, first_bad, 1, z_threshold(e, first_bad), e->z_T_now);
+            if (z_split_pairs > 0 && e->opts.z_pairs > 0) z_split_pairs = e->opts.z_pairs;
+        }
+        if (split || z_split_pairs > 0) {
+            const int n0 = z_split_pairs > 0 ? first_bad : (g.members + 1) / 2, n1 = g.members - n0;
             XCHK(make_half_view(e, 0, 0, n0));
             XCHK(make_half_view(e, 1, n0, n1));
             aim_half_view(e, e->half[0], 0);
             aim_half_view(e, e->half[1], n0);
+            if (z_split_pairs > 0) { e->half[0]->z_pairs_now = z_split_pairs; e->half[1]->z_pairs_now = 0; }
             HIPCHK(hipMemsetAsync(e->redo, 0, 2 * sizeof(int), s));
             HIPCHK(hipStreamSynchronize(s));                     // first guess, states and counters are in place
             int st2[2] = {XEE_OK, XEE_OK};
