@@ -1469,6 +1469,9 @@ int xee_ensemble_solve(xee_ensemble_t* e, int max_iter, int check_step, int conv
             // is through the other has the device -- tools/elig_split_probe.py, 16 + 8 cases: 39.2 ms with 1920 waves, 47.5 with 960; 32 + 16:
             // 1920 either way; the tiled sweep for all: 61.1 ms)
             z_split_pairs = sweep_z_pairs(gv, first_bad, 1, z_threshold(e, first_bad), e->z_T_now);
+            // (too few of them to fill the device: as one of two streams -- the 8 + 16 cases of the bench's source-term sweep, whose thermal
+            // kind has zeros in its forcing too)
+            if (z_split_pairs <= 0) z_split_pairs = sweep_z_pairs(gv, first_bad, 2, z_threshold(e, first_bad), e->z_T_now);
             if (z_split_pairs > 0 && e->opts.z_pairs > 0) z_split_pairs = e->opts.z_pairs;
         }
         if (split || z_split_pairs > 0) {
