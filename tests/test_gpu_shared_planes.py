@@ -278,3 +278,52 @@ def test_nine_weight_b_sums_the_hoisted_division_cannot_take_stay_tiled():
         got, rg, t = run(mem, {"kernel": 4})
         assert (t["z_launches"] > 0) == streams, (streams, t)
         assert biteq(got, want) and rg["err_now"].tobytes() == rw["err_now"].tobytes()
+
+
+def test_nine_weight_random_shapes_chunkings_and_lengths():
+    """Fifty random grids (8 .. 300 points a side: every alignment of the last strip of 56 and of the chunks against the two-row fetch
+    groups and the loop turn), two to five members that share A and C (each its own B, some with +0 patches), random chunk pairs,
+    check steps (blocks that are no whole number of 4-iteration launches: k_sweep_q takes the rest) and iteration counts, criteria
+    that stop some members early; k_sweep_z<nine> against k_sweep_q<nine>."""
+    rng = np.random.default_rng(20261006)
+    stopped = 0
+    for trial in range(50):
+        nr, nz = int(rng.integers(8, 301)), int(rng.integers(8, 301))
+        M = int(rng.integers(2, 6))
+        cs = int(rng.integers(12, 60))                      # (a block shorter than 8 + 4 iterations is all k_sweep_q's)
+        n = int(rng.integers(cs, 5 * cs))
+        pairs = int(rng.integers(0, 9))
+        ins = []
+        for m in range(M):
+            A, B, Cc, bc = H.member_inputs(nr, nz, 10 * trial + m)
+            if rng.random() < 0.3:
+                B = B.copy(); j0, i0 = int(rng.integers(0, nz - 2)), int(rng.integers(0, nr - 2))
+                B[j0: j0 + int(rng.integers(2, 40)), i0: i0 + int(rng.integers(2, 40))] = 0.0
+            ins.append((A, B, Cc, bc))
+        outs = {}
+        r1 = 1e-30
+        for k in (3, 4):
+            with xee.Ensemble(nr, nz, M) as e:
+                e.set_option("kernel", k); e.set_option("z_pairs", pairs)
+                e.set_profiles(xee.profiles(nr, nz))
+                for m, (A, B, Cc, bc) in enumerate(ins):
+                    for name, arr in (("A", A), ("B", B), ("C", Cc), ("BC_INIT", bc), ("FORCING", _forcing9(A, trial + m))):
+                        e.upload(name, arr, first=m)
+                e.assemble(1)
+                if k == 3 and trial % 3 == 0:               # a criterion between the members' first residuals: some stop at the first check
+                    probe = e.solve(cs, 1e-30, -1.0, 1.0, check_step=cs, converge_time=1)
+                    r1 = float(np.median(probe["err_now"]))
+                rec = e.solve(n, r1, -1.0, 1.0, check_step=cs, converge_time=1)
+                outs[k] = (e.download("PSI"), rec.copy(), e.download("RESIDUAL"), e.timing())
+        tz = outs[4][3]
+        assert tz["z_launches"] > 0 and tz["inline_redo_tiles"] == 0, (trial, nr, nz, M, cs, n, pairs, tz)
+        assert biteq(outs[4][0], outs[3][0]), (trial, nr, nz, M, cs, n, pairs)
+        assert outs[4][1]["err_now"].tobytes() == outs[3][1]["err_now"].tobytes() and outs[4][1]["iters"].tolist() == outs[3][1]["iters"].tolist()
+        assert biteq(outs[4][2][:, 1:-1, 1:-1], outs[3][2][:, 1:-1, 1:-1]), (trial, nr, nz, M, cs, n, pairs)
+        stopped += int(np.any(outs[3][1]["iters"] < n))
+    assert stopped >= 5, stopped
+
+
+def _forcing9(A, seed):
+    rng = np.random.default_rng(seed)
+    return ((0.5 + rng.random(A.shape)) * rng.choice(np.float32([-1e-9, 1e-9]), size=A.shape)).astype(np.float32)
