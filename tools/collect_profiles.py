@@ -19,6 +19,8 @@ def main():
     newest = lambda pattern: sorted(glob.glob(pattern, recursive=True), key=lambda f: Path(f).stat().st_mtime)[-1:]
     for f in newest(str(src / "stats" / "**" / "*kernel_stats.csv")):
         shutil.copy(f, dst / "final_kernel_stats.csv")
+    for f in newest(str(src / "stats_baroclinic" / "**" / "*kernel_stats.csv")):
+        shutil.copy(f, dst / "final_kernel_stats_baroclinic.csv")
     for wl_dir in sorted((src / "pmc").glob("*")):
         for p in ("fetch", "write", "sq1", "sq2", "tcc"):
             files = newest(str(wl_dir / p / "**" / "*counter_collection.csv"))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Measurement pass on the GPU box.  Usage: tools/profile_round.sh <tag> [workloads...]
-#   1. kernel-trace stats of the default bench (rocprofv3 --kernel-trace --stats)
+#   1. kernel-trace stats of the default bench and of --workload baroclinic (rocprofv3 --kernel-trace --stats)
 #   2. per workload: FETCH_SIZE pass, WRITE_SIZE pass (separate: TCC has 4 slots, the two need 3 + 2) and two SQ
 #      passes on the PRODUCTION kernels (tools/pmc_workload.py) -- counters only, no trace domains besides
 #      --kernel-trace (gpurun refuses --pmc mixed with sys/hip/hsa traces)
@@ -10,11 +10,12 @@ tag=$1; shift
 wls=${@:-ensemble baroclinic single highres}
 root=$(pwd)
 out=$root/gpurun_out/$tag
-rm -rf $out/stats $out/pmc $out/summary
+rm -rf $out/stats $out/stats_baroclinic $out/pmc $out/summary
 mkdir -p $out
 python3 $root/tools/build_hash.py > $out/build_hash.txt
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $root/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $out/bench_under_rocprof.json 2> $out/bench_under_rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_baroclinic -- python3 $root/bench.py --workload baroclinic --steps 1 --warmup 1 --no-cpu-baseline > $out/bench_baroclinic_under_rocprof.json 2> $out/bench_baroclinic_under_rocprof.err
 echo "stats done"
 SQ1="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAIT_ANY"
 SQ2="SQ_WAVES SQ_INSTS_SALU SQ_INSTS_VMEM SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_BUSY_CU_CYCLES"
